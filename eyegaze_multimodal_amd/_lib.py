@@ -1,0 +1,123 @@
+"""ctypes binding of libeyegaze_hip.so (C ABI declared in include/eyegaze_hip.h).
+
+The library is mandatory: importing this module without it raises.  There is NO CPU fallback anywhere in
+the package — the product path is the HIP path or nothing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libeyegaze_hip.so"
+
+EG_F32, EG_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+ABI_VERSION = 1
+
+
+class EgError(RuntimeError):
+    pass
+
+
+class RowMap(C.Structure):
+    _fields_ = [("row_stride", C.c_int64), ("group_stride", C.c_int64), ("rows_per_group", C.c_int32), ("_pad", C.c_int32)]
+
+
+def rowmap(row_stride: int, group_stride: int = 0, rows_per_group: int = 0) -> RowMap:
+    return RowMap(int(row_stride), int(group_stride), int(rows_per_group), 0)
+
+
+class StepState(C.Structure):
+    _fields_ = [("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32), ("lr", C.c_float), ("bias_corr1", C.c_float),
+                ("bias_corr2", C.c_float), ("grad_scale", C.c_float), ("clip_coef", C.c_float), ("grad_norm", C.c_float)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
+                ("gate", C.c_void_p), ("out_pre", C.c_void_p), ("state", C.c_void_p),
+                ("a", RowMap), ("c", RowMap), ("r", RowMap), ("p", RowMap),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldw", C.c_int32),
+                ("act", C.c_int32), ("dtype", C.c_int32),
+                ("drop1_p", C.c_float), ("drop2_p", C.c_float), ("drop1_site", C.c_uint32), ("drop2_site", C.c_uint32),
+                ("gate_scale", C.c_float)]
+
+
+class GemmTNDesc(C.Structure):
+    _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("partial", C.c_void_p), ("y", RowMap), ("x", RowMap),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("splits", C.c_int32), ("dtype", C.c_int32)]
+
+
+_P, _I, _L, _F, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
+
+# name -> argtypes; every function returns int (0 = ok).  Mirrors include/eyegaze_hip.h exactly.
+SIGNATURES = {
+    "eg_device_info": [C.POINTER(C.c_int), C.c_char_p, _I],
+    "eg_window_pack": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "eg_cast": [_P, _P, _L, _I, _P],
+    "eg_transpose_cast": [_P, _P, _I, _I, _I, _I, _P],
+    "eg_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "eg_pack_convT_weight": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "eg_gemm_nt": [C.POINTER(GemmDesc), _P],
+    "eg_gemm_tn": [C.POINTER(GemmTNDesc), _P],
+    "eg_reduce_partials": [_P, _P, _L, _I, _L, _I, _P],
+    "eg_unpack_conv_wgrad": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "eg_colsum": [_P, RowMap, _I, _I, _P, _I, _I, _P],
+    "eg_layernorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "eg_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U, _F, _U, _P, _P],
+    "eg_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _P, _P],
+    "eg_attention_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _P, _P],
+    "eg_rows_bcast_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "eg_rows_copy": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "eg_pool_fuse_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "eg_pool_fuse_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "eg_classifier_ce_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "eg_classifier_ce_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "eg_batch_rowsum": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "eg_rows_gather_gate": [_P, _P, _P, RowMap, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "eg_grad_sqnorm": [_P, _L, _P, _I, _P],
+    "eg_clip_coef": [_P, _I, _F, _P, _P],
+    "eg_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P],
+    "eg_fill_f32": [_P, _L, _F, _P],
+}
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads the library once; raises EgError when it is missing or its ABI differs (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise EgError(f"{LIB_PATH} is missing: build it with `python -m eyegaze_multimodal_amd.build` "
+                      "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    l = C.CDLL(str(LIB_PATH))
+    l.eg_abi_version.restype = C.c_int
+    if l.eg_abi_version() != ABI_VERSION:
+        raise EgError(f"ABI mismatch: library {l.eg_abi_version()} vs binding {ABI_VERSION}")
+    l.eg_last_error.restype = C.c_char_p
+    for name, args in SIGNATURES.items():
+        fn = getattr(l, name, None)
+        if fn is None:
+            continue  # optional (not yet built) entry points are reported by exported_symbols()
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = l
+    return l
+
+
+def exported_symbols():
+    l = lib()
+    return {n: hasattr(l, n) for n in list(SIGNATURES) + ["eg_abi_version", "eg_last_error"]}
+
+
+def call(name: str, *args):
+    l = lib()
+    rc = getattr(l, name)(*args)
+    if rc != 0:
+        raise EgError(f"{name}: {l.eg_last_error().decode()}")
+
+
+def ptr(t) -> int:
+    """Device (or host) address of a torch tensor / None."""
+    return 0 if t is None else t.data_ptr()

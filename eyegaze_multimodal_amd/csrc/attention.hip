@@ -1,0 +1,382 @@
+// Multi-head attention core for short sequences (S <= 160, d_k = 32) on gfx950.
+// One wave owns one (sample, head): the whole S x S score matrix of a head lives in that wave's registers.
+//   scores^T tile = K_tile(16 keys x 32) * Q_tile^T            -> v_mfma_f32_16x16x32_bf16, key on rows, query on lanes
+//   soft-max over keys = in-register over tiles + 2 cross-lane steps (lanes l, l^16, l^32, l^48 share a query)
+//   O^T = V^T * P^T: the score accumulators ARE the P^T operand (no LDS round trip); V^T fragments come from a
+//   row-major LDS image through ds_read_b64_tr_b16 with the key permutation the accumulator layout implies:
+//   k-slot 8g+j  <->  key 32*kp + 16*(j>>2) + 4g + (j&3).
+// Backward recomputes P from the saved log-sum-exp (flash style): pass A (key rows / query lanes) gives dQ,
+// pass B (query rows / key lanes) gives dK and dV; delta = rowsum(dO * O).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ bf16x8 ld_frag_global(const bf16_t* p, bool valid) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (valid) v = *(const u32x4*)p;
+  return __builtin_bit_cast(bf16x8, v);
+}
+// LDS image: [rows][32 bf16] = 64-B rows; the two 32-B halves of a row are swapped when (row>>2)&1 so that the
+// transposed reads of 8 consecutive rows hit 8 distinct 32-B slots of the 256-B bank row.
+__device__ __forceinline__ int img_chunk_off(int row, int c4) {
+  return row * 64 + ((((c4 >> 1) ^ ((row >> 2) & 1))) << 5) + ((c4 & 1) << 4);
+}
+__device__ __forceinline__ bf16x8 ld_frag_lds_row(const char* img, int row, int g) {
+  return *(const bf16x8*)(img + img_chunk_off(row, g));
+}
+// transposed fragment: slot 8g+j <-> row rbase + 16*(j>>2) + 4g + (j&3), column d0 + (lane&15)
+__device__ __forceinline__ bf16x8 ld_frag_lds_tr(const char* img, int rbase, int dt, int lane) {
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  s16x4 part[2];
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    const int row = rbase + 16 * h2 + 4 * g + qq;
+    const int off = row * 64 + ((dt ^ (g & 1)) << 5) + pp * 8;
+    part[h2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(img + off));
+  }
+  s16x8 t = {part[0][0], part[0][1], part[0][2], part[0][3], part[1][0], part[1][1], part[1][2], part[1][3]};
+  return __builtin_bit_cast(bf16x8, t);
+}
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
+  u32x4 v;
+  v[0] = pack2bf(a[0], a[1]);
+  v[1] = pack2bf(a[2], a[3]);
+  v[2] = pack2bf(b[0], b[1]);
+  v[3] = pack2bf(b[2], b[3]);
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ void stage_rows(char* img, const bf16_t* src, long long ld, int S, int SP, int lane) {
+  for (int id = lane; id < SP * 4; id += 64) {
+    const int row = id >> 2, c4 = id & 3;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < S) v = *(const u32x4*)(src + (long long)row * ld + c4 * 8);
+    *(u32x4*)(img + img_chunk_off(row, c4)) = v;
+  }
+}
+
+constexpr float kScale = 0.17677669529663687f;  // 1/sqrt(32)
+
+template <int SP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                       float* __restrict__ lse, int NB, int S, int H, int kv_shift,
+                                                       DropCfg dc, const eg_step_state* st) {
+  constexpr int NKT = SP / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  int pid = blockIdx.x * 4 + wave;
+  const bool valid = pid < NB * H;
+  if (!valid) pid = NB * H - 1;
+  const int b = pid / H, h = pid % H;
+  const int bk = (b + kv_shift) % NB;
+  const int D = H * 32;
+  const long long ld = 3ll * D;
+  const bf16_t* qbase = qkv + (long long)b * S * ld + h * 32;
+  const bf16_t* kbase = qkv + (long long)bk * S * ld + D + h * 32;
+  const bf16_t* vbase = kbase + D;
+  char* vimg = smem + wave * (SP * 64);
+  stage_rows(vimg, vbase, ld, S, SP, lane);
+  const int nkt = (S + 15) >> 4;
+  bf16x8 kf[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const int key = kt * 16 + l15;
+    kf[kt] = ld_frag_global(kbase + (long long)key * ld + g * 8, key < S);
+  }
+  uint32_t seed_lo = 0, seed_hi = 0;
+  if (dc.thresh) { seed_lo = st->seed_lo; seed_hi = st->seed_hi; }
+  __syncthreads();
+  for (int qt = 0; qt < nkt; ++qt) {
+    const int q = qt * 16 + l15;
+    const bf16x8 qf = ld_frag_global(qbase + (long long)q * ld + g * 8, q < S);
+    f32x4 s[NKT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (kt < nkt) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf, s[kt], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        const float v = key < S ? s[kt][r] * kScale : -INFINITY;
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(s[kt][r] - mx);
+        s[kt][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (g == 0 && q < S && valid) lse[((long long)b * H + h) * S + q] = mx + __logf(sum);
+    const uint32_t rowidx = (uint32_t)((b * H + h) * S + q) * (uint32_t)S;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = s[kt][r] * inv;
+        if (dc.thresh) p = eg_dropout(p, dc, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g + r));
+        s[kt][r] = p;
+      }
+    f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kp = 0; kp < NKT / 2; ++kp) {
+      if (2 * kp < nkt) {
+        const bf16x8 pf = pack_frag(s[2 * kp], s[2 * kp + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 vf = ld_frag_lds_tr(vimg, 32 * kp, dt, lane);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (q < S && valid) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        float v[4] = {o[dt][0], o[dt][1], o[dt][2], o[dt][3]};
+        store4(ctx + ((long long)b * S + q) * D + h * 32 + 16 * dt + 4 * g, v);
+      }
+    }
+  }
+}
+
+template <int SP>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
+                                                       const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
+                                                       bf16_t* __restrict__ dqkv, int NB, int S, int H, int kv_shift,
+                                                       DropCfg dc, const eg_step_state* st) {
+  constexpr int NKT = SP / 16;
+  constexpr int WB = 3 * SP * 64 + 2 * SP * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  int pid = blockIdx.x * 4 + wave;
+  const bool valid = pid < NB * H;
+  if (!valid) pid = NB * H - 1;
+  const int b = pid / H, h = pid % H;
+  const int bk = (b + kv_shift) % NB;
+  const int D = H * 32;
+  const long long ld = 3ll * D;
+  const bf16_t* qbase = qkv + (long long)b * S * ld + h * 32;
+  const bf16_t* kbase = qkv + (long long)bk * S * ld + D + h * 32;
+  const bf16_t* vbase = kbase + D;
+  const bf16_t* dobase = dctx + (long long)b * S * D + h * 32;
+  const bf16_t* obase = ctx + (long long)b * S * D + h * 32;
+  char* base = smem + wave * WB;
+  char* qimg = base;
+  char* kimg = base + SP * 64;
+  char* doimg = base + 2 * SP * 64;
+  float* lsel = (float*)(base + 3 * SP * 64);
+  float* dl = lsel + SP;
+  stage_rows(qimg, qbase, ld, S, SP, lane);
+  stage_rows(kimg, kbase, ld, S, SP, lane);
+  stage_rows(doimg, dobase, D, S, SP, lane);
+  for (int q = lane; q < SP; q += 64) {
+    float l = 0.f, dsum = 0.f;
+    if (q < S) {
+      l = lse[((long long)b * H + h) * S + q];
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        float a[8], o[8];
+        load8(dobase + (long long)q * D + c4 * 8, a);
+        load8(obase + (long long)q * D + c4 * 8, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += a[e] * o[e];
+      }
+    }
+    lsel[q] = l;
+    dl[q] = dsum;
+  }
+  const int nkt = (S + 15) >> 4;
+  bf16x8 kf[NKT], vf[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const int key = kt * 16 + l15;
+    kf[kt] = ld_frag_global(kbase + (long long)key * ld + g * 8, key < S);
+    vf[kt] = ld_frag_global(vbase + (long long)key * ld + g * 8, key < S);
+  }
+  uint32_t seed_lo = 0, seed_hi = 0;
+  if (dc.thresh) { seed_lo = st->seed_lo; seed_hi = st->seed_hi; }
+  const uint32_t headidx = (uint32_t)((b * H + h) * S);
+  __syncthreads();
+
+  // ---- pass A: key rows / query lanes -> dQ ----
+  for (int qt = 0; qt < nkt; ++qt) {
+    const int q = qt * 16 + l15;
+    const bf16x8 qf = ld_frag_lds_row(qimg, q, g);
+    const bf16x8 dof = ld_frag_lds_row(doimg, q, g);
+    const float lq = lsel[q], dq = dl[q];
+    const uint32_t rowidx = (headidx + (uint32_t)q) * (uint32_t)S;
+    f32x4 ds[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      ds[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (kt < nkt) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 sT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf, z, 0, 0, 0);
+        const f32x4 dpT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kt], dof, z, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * g + r;
+          const float p = key < S ? __expf(sT[r] * kScale - lq) : 0.f;
+          float dp = dpT[r];
+          if (dc.thresh) dp = eg_dropout(dp, dc, seed_lo, seed_hi, rowidx + (uint32_t)key);
+          ds[kt][r] = p * (dp - dq);
+        }
+      }
+    }
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kp = 0; kp < NKT / 2; ++kp) {
+      if (2 * kp < nkt) {
+        const bf16x8 dsf = pack_frag(ds[2 * kp], ds[2 * kp + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 ktr = ld_frag_lds_tr(kimg, 32 * kp, dt, lane);
+          acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr, dsf, acc[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (q < S && valid) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        float v[4] = {acc[dt][0] * kScale, acc[dt][1] * kScale, acc[dt][2] * kScale, acc[dt][3] * kScale};
+        store4(dqkv + ((long long)b * S + q) * ld + h * 32 + 16 * dt + 4 * g, v);
+      }
+    }
+  }
+
+  // ---- pass B: query rows / key lanes -> dK, dV ----
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int key = kt * 16 + l15;
+    f32x4 dk[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 dv[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    // kf/vf are indexed with a runtime kt here: pick the fragment with a uniform select chain (no scratch)
+    bf16x8 kfr = kf[0], vfr = vf[0];
+#pragma unroll
+    for (int i = 1; i < NKT; ++i)
+      if (i == kt) { kfr = kf[i]; vfr = vf[i]; }
+#pragma unroll
+    for (int qp = 0; qp < NKT / 2; ++qp) {
+      if (2 * qp < nkt) {
+        f32x4 pd2[2], ds2[2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int qt = 2 * qp + h2;
+          pd2[h2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          ds2[h2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (qt < nkt) {
+            const bf16x8 qrow = ld_frag_lds_row(qimg, qt * 16 + l15, g);
+            const bf16x8 dorow = ld_frag_lds_row(doimg, qt * 16 + l15, g);
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qrow, kfr, z, 0, 0, 0);
+            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dorow, vfr, z, 0, 0, 0);
+            const f32x4 l4 = *(const f32x4*)(lsel + qt * 16 + 4 * g);
+            const f32x4 d4 = *(const f32x4*)(dl + qt * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int qq = qt * 16 + 4 * g + r;
+              const float p = (key < S && qq < S) ? __expf(s[r] * kScale - l4[r]) : 0.f;
+              float m = 1.0f;
+              if (dc.thresh) m = eg_dropout(1.0f, dc, seed_lo, seed_hi, (headidx + (uint32_t)qq) * (uint32_t)S + (uint32_t)key);
+              pd2[h2][r] = p * m;
+              ds2[h2][r] = p * (dp[r] * m - d4[r]);
+            }
+          }
+        }
+        const bf16x8 pdf = pack_frag(pd2[0], pd2[1]);
+        const bf16x8 dsf = pack_frag(ds2[0], ds2[1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 dotr = ld_frag_lds_tr(doimg, 32 * qp, dt, lane);
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr, pdf, dv[dt], 0, 0, 0);
+          const bf16x8 qtr = ld_frag_lds_tr(qimg, 32 * qp, dt, lane);
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr, dsf, dk[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (key < S && valid) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        float a[4] = {dk[dt][0] * kScale, dk[dt][1] * kScale, dk[dt][2] * kScale, dk[dt][3] * kScale};
+        float c[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
+        bf16_t* row = dqkv + ((long long)bk * S + key) * ld + h * 32 + 16 * dt + 4 * g;
+        store4(row + D, a);
+        store4(row + 2 * D, c);
+      }
+    }
+  }
+}
+
+template <int SP>
+int launch_fwd(const void* qkv, void* ctx, float* lse, int NB, int S, int H, int kv_shift, DropCfg dc,
+               const eg_step_state* st, hipStream_t s) {
+  const int nblk = (NB * H + 3) / 4;
+  hipLaunchKernelGGL(attn_fwd_kernel<SP>, dim3(nblk), dim3(256), 4 * SP * 64, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse,
+                     NB, S, H, kv_shift, dc, st);
+  return 0;
+}
+template <int SP>
+int launch_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int NB, int S, int H,
+               int kv_shift, DropCfg dc, const eg_step_state* st, hipStream_t s) {
+  const int nblk = (NB * H + 3) / 4;
+  constexpr int lds = 4 * (3 * SP * 64 + 2 * SP * 4);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)attn_bwd_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel<SP>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)qkv, (const bf16_t*)ctx,
+                     (const bf16_t*)dctx, lse, (bf16_t*)dqkv, NB, S, H, kv_shift, dc, st);
+  return 0;
+}
+
+}  // namespace
+
+static int attn_check(const char* who, int NB, int S, int H, int kv_shift, int dtype, float p, const void* st) {
+  EG_CHECK(NB > 0 && S > 0 && H > 0, "%s: bad shape NB=%d S=%d H=%d", who, NB, S, H);
+  EG_CHECK(S <= 160, "%s: S=%d exceeds the register-resident limit of 160", who, S);
+  EG_CHECK(kv_shift >= 0 && kv_shift < NB, "%s: kv_shift=%d out of range", who, kv_shift);
+  EG_CHECK(dtype == EG_BF16, "%s: only EG_BF16 is implemented for the attention core (dtype=%d)", who, dtype);
+  EG_CHECK(p >= 0.f && p < 1.f && (p == 0.f || st), "%s: dropout p=%f needs a step state", who, (double)p);
+  EG_CHECK((long long)NB * H * S * S < (1ll << 32), "%s: NB*H*S*S exceeds the 32-bit dropout index", who);
+  return 0;
+}
+
+extern "C" int eg_attention_fwd(const void* qkv, void* ctx, float* lse, int NB, int S, int H, int kv_shift, int dtype,
+                                float drop_p, uint32_t drop_site, const eg_step_state* state, void* stream) {
+  EG_CHECK(qkv && ctx && lse, "eg_attention_fwd: null pointer");
+  if (attn_check("eg_attention_fwd", NB, S, H, kv_shift, dtype, drop_p, state)) return 1;
+  DropCfg dc = make_drop(drop_p, drop_site);
+  hipStream_t s = (hipStream_t)stream;
+  if (S <= 96) launch_fwd<96>(qkv, ctx, lse, NB, S, H, kv_shift, dc, state, s);
+  else if (S <= 128) launch_fwd<128>(qkv, ctx, lse, NB, S, H, kv_shift, dc, state, s);
+  else launch_fwd<160>(qkv, ctx, lse, NB, S, H, kv_shift, dc, state, s);
+  EG_LAUNCH_CHECK("attention_fwd");
+  return 0;
+}
+
+extern "C" int eg_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int NB,
+                                int S, int H, int kv_shift, int dtype, float drop_p, uint32_t drop_site,
+                                const eg_step_state* state, void* stream) {
+  EG_CHECK(qkv && ctx && dctx && lse && dqkv, "eg_attention_bwd: null pointer");
+  if (attn_check("eg_attention_bwd", NB, S, H, kv_shift, dtype, drop_p, state)) return 1;
+  DropCfg dc = make_drop(drop_p, drop_site);
+  hipStream_t s = (hipStream_t)stream;
+  if (S <= 96) launch_bwd<96>(qkv, ctx, dctx, lse, dqkv, NB, S, H, kv_shift, dc, state, s);
+  else if (S <= 128) launch_bwd<128>(qkv, ctx, dctx, lse, dqkv, NB, S, H, kv_shift, dc, state, s);
+  else launch_bwd<160>(qkv, ctx, dctx, lse, dqkv, NB, S, H, kv_shift, dc, state, s);
+  EG_LAUNCH_CHECK("attention_bwd");
+  return 0;
+}

@@ -1,0 +1,171 @@
+// Common device helpers for the gfx950 (MI355X / CDNA4) kernels of the dual-stream window classifier.
+// Wave = 64 lanes everywhere.  No CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/eyegaze_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+typedef uint16_t bf16_t;  // storage type for bf16 tensors
+
+#define EG_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (host)
+// ---------------------------------------------------------------------------------------------
+extern thread_local char eg_err_buf[512];
+int eg_fail(const char* fmt, ...);
+#define EG_CHECK(cond, ...)            \
+  do {                                 \
+    if (!(cond)) return eg_fail(__VA_ARGS__); \
+  } while (0)
+#define EG_LAUNCH_CHECK(name)                                                      \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) return eg_fail("%s launch: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// bf16 <-> f32
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  // round-to-nearest-even via the hardware convert (NaN stays NaN)
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kPer16B = 4;
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int kPer16B = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// load / store 8 consecutive elements as floats (pointer must be 16-B aligned for bf16, 32-B region for f32)
+__device__ __forceinline__ void load8(const float* p, float v[8]) {
+  f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float v[8]) {
+  u32x4 a = *(const u32x4*)p;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(a[i] << 16);
+    v[2 * i + 1] = __uint_as_float(a[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void store8(float* p, const float v[8]) {
+  f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+  *(f32x4*)p = a;
+  *(f32x4*)(p + 4) = b;
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float v[8]) {
+  u32x4 a;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+  *(u32x4*)p = a;
+}
+__device__ __forceinline__ void load4(const float* p, float v[4]) {
+  f32x4 a = *(const f32x4*)p;
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float v[4]) {
+  u32x2 a = *(const u32x2*)p;
+  v[0] = __uint_as_float(a[0] << 16); v[1] = __uint_as_float(a[0] & 0xffff0000u);
+  v[2] = __uint_as_float(a[1] << 16); v[3] = __uint_as_float(a[1] & 0xffff0000u);
+}
+__device__ __forceinline__ void store4(float* p, const float v[4]) {
+  f32x4 a = {v[0], v[1], v[2], v[3]};
+  *(f32x4*)p = a;
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
+  u32x2 a;
+  a[0] = pack2bf(v[0], v[1]);
+  a[1] = pack2bf(v[2], v[3]);
+  *(u32x2*)p = a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// counter-based dropout mask.  One 32-bit hash per element; identical in forward and backward
+// because it depends only on (seed, site, element index).  keep <=> low 24 bits >= p * 2^24.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t eg_hash(uint32_t seed_lo, uint32_t seed_hi, uint32_t site, uint32_t idx) {
+  uint32_t x = idx ^ (site * 0x9E3779B9u) ^ seed_lo;
+  x *= 0x85EBCA6Bu; x ^= x >> 13;
+  x += seed_hi;
+  x *= 0xC2B2AE35u; x ^= x >> 16;
+  x *= 0x27D4EB2Fu; x ^= x >> 15;
+  return x;
+}
+struct DropCfg {
+  uint32_t thresh;  // round(p * 2^24); 0 = disabled
+  float scale;      // 1/(1-p)
+  uint32_t site;
+};
+__device__ __forceinline__ float eg_dropout(float v, const DropCfg& d, uint32_t seed_lo, uint32_t seed_hi, uint32_t idx) {
+  if (d.thresh == 0) return v;
+  uint32_t h = eg_hash(seed_lo, seed_hi, d.site, idx) & 0xFFFFFFu;
+  return h >= d.thresh ? v * d.scale : 0.0f;
+}
+static inline DropCfg make_drop(float p, uint32_t site) {
+  DropCfg d;
+  d.thresh = p > 0.f ? (uint32_t)(p * 16777216.0f + 0.5f) : 0u;
+  d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  d.site = site;
+  return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave reductions (64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware bijective remap of a linear block id (8 XCDs, round-robin dispatch): blocks that are
+// neighbours after the remap share an XCD (and its L2).  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// grouped row addressing: row r of a logical [M, *] matrix lives at
+//   base + (r / rows_per_group) * group_stride + (r % rows_per_group) * row_stride   (elements)
+struct RowMap {
+  long long row_stride;
+  long long group_stride;
+  int rows_per_group;  // 0 => plain (r * row_stride)
+};
+__device__ __forceinline__ long long row_off(const RowMap& m, int r) {
+  if (m.rows_per_group <= 0) return (long long)r * m.row_stride;
+  int g = r / m.rows_per_group;
+  return (long long)g * m.group_stride + (long long)(r - g * m.rows_per_group) * m.row_stride;
+}
+static inline RowMap to_rowmap(const eg_rowmap& m) {
+  RowMap r;
+  r.row_stride = m.row_stride;
+  r.group_stride = m.group_stride;
+  r.rows_per_group = m.rows_per_group;
+  return r;
+}

@@ -1,0 +1,540 @@
+// MFMA GEMMs for gfx950.
+//   gemm_nt_kernel : C[M,N] = epilogue(A[M,K] * W[N,K]^T)   (forward linears, strided-conv rows, backward-data)
+//   gemm_tn_kernel : P[s][N,K] = sum_{m in split s} dY[m,n] * X[m,k]   (weight gradients, split over M)
+// 128x128 output tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16 tiles.
+//   bf16: v_mfma_f32_16x16x32_bf16, K-tile 64      f32: v_mfma_f32_16x16x4_f32 (exact fmaf chain), K-tile 32
+// LDS rows are 128 B wide with a 16-B-chunk XOR swizzle so ds_read_b128 fragment reads are conflict-free.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int CT_PITCH = 132;                      // fp32 epilogue tile pitch (floats): 128 + 4
+constexpr int NT_LDS_BYTES = BM * CT_PITCH * 4;    // 67584 >= 2 * 32 KiB staging
+
+template <typename T>
+struct GemmNT {
+  const T* A; const T* W; T* C; const float* bias; const T* residual; const T* gate; T* out_pre;
+  const eg_step_state* st;
+  RowMap a, c, r, pm;
+  int M, N, K, ldw, act, tiles_n, nblocks;
+  DropCfg d1, d2;
+  float gate_scale;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == EG_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == EG_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ void mma_ktile(const char* bufA, const char* bufW, int wm, int wn, int lane, f32x4 (&acc)[4][4]);
+
+template <>
+__device__ __forceinline__ void mma_ktile<bf16_t>(const char* bufA, const char* bufW, int wm, int wn, int lane,
+                                                  f32x4 (&acc)[4][4]) {
+  const int l15 = lane & 15, g = lane >> 4, sw = lane & 7;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int ch = ((kk * 4 + g) ^ sw) << 4;
+    bf16x8 xf[4], wf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xf[i] = *(const bf16x8*)(bufA + (wm * 64 + i * 16 + l15) * 128 + ch);
+      wf[i] = *(const bf16x8*)(bufW + (wn * 64 + i * 16 + l15) * 128 + ch);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+  }
+}
+
+template <>
+__device__ __forceinline__ void mma_ktile<float>(const char* bufA, const char* bufW, int wm, int wn, int lane,
+                                                 f32x4 (&acc)[4][4]) {
+  const int l15 = lane & 15, g = lane >> 4, sw = lane & 7;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int ch = ((s ^ sw) << 4) + g * 4;
+    float xf[4], wf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xf[i] = *(const float*)(bufA + (wm * 64 + i * 16 + l15) * 128 + ch);
+      wf[i] = *(const float*)(bufW + (wn * 64 + i * 16 + l15) * 128 + ch);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int EPB = 16 / sizeof(T);  // elements per 16-B chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bid = xcd_remap(blockIdx.x, p.nblocks);
+  const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
+
+  // staging: each thread moves 4 x 16 B of the A tile and 4 x 16 B of the W tile per K-tile
+  const int crow = tid >> 3, cch = tid & 7;
+  const char* ap[4];
+  const char* wp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = crow + 32 * i;
+    const int m = min(m0 + row, p.M - 1);
+    const int n = min(n0 + row, p.N - 1);
+    ap[i] = (const char*)(p.A + row_off(p.a, m)) + cch * 16;
+    wp[i] = (const char*)(p.W + (long long)n * p.ldw) + cch * 16;
+  }
+  const int soff = crow * 128 + ((cch ^ (crow & 7)) << 4);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / (128 / (int)sizeof(T));
+  u32x4 ra[4], rw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ra[i] = *(const u32x4*)(ap[i]);
+    rw[i] = *(const u32x4*)(wp[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *(u32x4*)(smem + soff + i * 4096) = ra[i];
+    *(u32x4*)(smem + 16384 + soff + i * 4096) = rw[i];
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = *(const u32x4*)(ap[i] + (size_t)(kt + 1) * 128);
+        rw[i] = *(const u32x4*)(wp[i] + (size_t)(kt + 1) * 128);
+      }
+    }
+    mma_ktile<T>(smem + cur * 32768, smem + cur * 32768 + 16384, wm, wn, lane, acc);
+    if (more) {
+      char* nb = smem + (cur ^ 1) * 32768;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *(u32x4*)(nb + soff + i * 4096) = ra[i];
+        *(u32x4*)(nb + 16384 + soff + i * 4096) = rw[i];
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: accumulators -> fp32 LDS tile -> row-wise 8-element chunks with fused bias/act/gate/dropout/residual
+  float* ct = (float*)smem;
+  {
+    const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        *(f32x4*)(ct + (wm * 64 + mi * 16 + l15) * CT_PITCH + wn * 64 + ni * 16 + 4 * g) = acc[ni][mi];
+  }
+  __syncthreads();
+  uint32_t seed_lo = 0, seed_hi = 0;
+  if (p.d1.thresh | p.d2.thresh) {
+    seed_lo = p.st->seed_lo;
+    seed_hi = p.st->seed_hi;
+  }
+  const int ch = tid & 15;
+  const int n = n0 + ch * 8;
+  if (n < p.N) {
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+    if (p.bias) load8(p.bias + n, bv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = (tid >> 4) + 16 * i;
+      const int m = m0 + row;
+      if (m >= p.M) continue;
+      float v[8];
+      load8(ct + row * CT_PITCH + ch * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bv[j], p.act);
+      const long long coff = row_off(p.c, m) + n;
+      if (p.gate) {
+        float gv[8];
+        load8(p.gate + coff, gv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gv[j] > 0.f ? v[j] * p.gate_scale : 0.f;
+      }
+      if (p.d1.thresh | p.d2.thresh) {
+        const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[j] = eg_dropout(v[j], p.d1, seed_lo, seed_hi, idx + j);
+          v[j] = eg_dropout(v[j], p.d2, seed_lo, seed_hi, idx + j);
+        }
+      }
+      if (p.out_pre) store8(p.out_pre + row_off(p.pm, m) + n, v);
+      if (p.residual) {
+        float rv[8];
+        load8(p.residual + row_off(p.r, m) + n, rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += rv[j];
+      }
+      store8(p.C + coff, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN (weight gradient).  LDS tiles hold [32 reduction rows][128 columns]; bf16 fragments are gathered
+// with ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, delivered column-major).
+// chunk swizzle f(r) = 2*((r&3) | ((r>>1)&4)): the 8 rows one half-wave touches land on 8 distinct
+// 32-B slots of the 256-B bank row, so the transposed reads are conflict-free.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct GemmTN {
+  const T* dY; const T* X; float* partial;
+  RowMap y, x;
+  int M, N, K, splits, rows_per_split, tiles_k, tiles_nk;
+};
+
+__device__ __forceinline__ int tn_swz(int r) { return (((r & 3) | ((r >> 1) & 4)) << 1); }
+
+template <typename T> struct TNCfg;
+template <> struct TNCfg<bf16_t> { static constexpr int ROWB = 256; static constexpr int CHUNKS = 16; };
+template <> struct TNCfg<float> { static constexpr int ROWB = 512; static constexpr int CHUNKS = 32; };
+
+template <typename T>
+__device__ __forceinline__ void tn_mma(const char* bufY, const char* bufX, int wn, int wk, int lane, f32x4 (&acc)[4][4]);
+
+template <>
+__device__ __forceinline__ void tn_mma<bf16_t>(const char* bufY, const char* bufX, int wn, int wk, int lane,
+                                               f32x4 (&acc)[4][4]) {
+  // lane (g = lane>>4, q = (lane&15)>>2, p = lane&3) addresses row 8g+4h+q, columns base+4p..4p+3
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  bf16x8 yf[4], xf[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s16x4 lo[2], hi[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = 8 * g + 4 * h + q;
+      const int f = tn_swz(r);
+      const int cy = (wn * 64 + i * 16 + 4 * pp);  // column (elements)
+      const int cx = (wk * 64 + i * 16 + 4 * pp);
+      const int ay = r * 256 + ((((cy >> 3) ^ f)) << 4) + ((cy >> 2) & 1) * 8;
+      const int ax = r * 256 + ((((cx >> 3) ^ f)) << 4) + ((cx >> 2) & 1) * 8;
+      lo[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bufY + ay));
+      hi[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bufX + ax));
+    }
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 ty = {lo[0][0], lo[0][1], lo[0][2], lo[0][3], lo[1][0], lo[1][1], lo[1][2], lo[1][3]};
+    s16x8 tx = {hi[0][0], hi[0][1], hi[0][2], hi[0][3], hi[1][0], hi[1][1], hi[1][2], hi[1][3]};
+    yf[i] = __builtin_bit_cast(bf16x8, ty);
+    xf[i] = __builtin_bit_cast(bf16x8, tx);
+  }
+#pragma unroll
+  for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+      acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ki], yf[ni], acc[ki][ni], 0, 0, 0);
+}
+
+template <>
+__device__ __forceinline__ void tn_mma<float>(const char* bufY, const char* bufX, int wn, int wk, int lane,
+                                              f32x4 (&acc)[4][4]) {
+  const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int r = 4 * s + g;
+    const int f = tn_swz(r);
+    float yf[4], xf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cy = wn * 64 + i * 16 + l15, cx = wk * 64 + i * 16 + l15;
+      yf[i] = *(const float*)(bufY + r * 512 + (((cy >> 2) ^ f) << 4) + (cy & 3) * 4);
+      xf[i] = *(const float*)(bufX + r * 512 + (((cx >> 2) ^ f) << 4) + (cx & 3) * 4);
+    }
+#pragma unroll
+    for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[ki], yf[ni], acc[ki][ni], 0, 0, 0);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWB = TNCfg<T>::ROWB;          // bytes per LDS tile row (128 columns)
+  constexpr int CHUNKS = TNCfg<T>::CHUNKS;      // 16-B chunks per row
+  constexpr int EPC = 16 / (int)sizeof(T);      // elements per chunk
+  constexpr int TILEB = 32 * ROWB;              // one operand tile
+  constexpr int PER_THREAD = 32 * CHUNKS / 256; // chunks per thread per operand (2 bf16, 4 f32)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave >> 1, wn = wave & 1;
+  const int split = blockIdx.x / p.tiles_nk;
+  const int t = blockIdx.x % p.tiles_nk;
+  const int n0 = (t / p.tiles_k) * 128, k0 = (t % p.tiles_k) * 128;
+  const int mbeg = split * p.rows_per_split;
+  const int mend = min(p.M, mbeg + p.rows_per_split);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // staging map: chunk id c = tid + 256*i -> row = c / CHUNKS, chunk-in-row = c % CHUNKS
+  u32x4 ry[PER_THREAD], rx[PER_THREAD];
+  auto load_tile = [&](int mt) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c / CHUNKS, ch = c % CHUNKS;
+      const int m = mt + row;
+      const bool rv = m < mend;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      ry[i] = z;
+      rx[i] = z;
+      if (rv && n0 + ch * EPC < p.N) ry[i] = *(const u32x4*)(p.dY + row_off(p.y, m) + n0 + ch * EPC);
+      if (rv && k0 + ch * EPC < p.K) rx[i] = *(const u32x4*)(p.X + row_off(p.x, m) + k0 + ch * EPC);
+    }
+  };
+  auto store_tile = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c / CHUNKS, ch = c % CHUNKS;
+      const int off = row * ROWB + ((ch ^ tn_swz(row)) << 4);
+      *(u32x4*)(buf + off) = ry[i];
+      *(u32x4*)(buf + TILEB + off) = rx[i];
+    }
+  };
+  const int nt = (mend - mbeg + 31) / 32;
+  if (nt > 0) {
+    load_tile(mbeg);
+    store_tile(smem);
+  }
+  __syncthreads();
+  for (int it = 0; it < nt; ++it) {
+    const int cur = it & 1;
+    const bool more = it + 1 < nt;
+    if (more) load_tile(mbeg + (it + 1) * 32);
+    tn_mma<T>(smem + cur * 2 * TILEB, smem + cur * 2 * TILEB + TILEB, wn, wk, lane, acc);
+    if (more) store_tile(smem + (cur ^ 1) * 2 * TILEB);
+    __syncthreads();
+  }
+  // D[i = k][j = n]: lane holds 4 consecutive k (rows 4g+r) for column n = lane&15
+  float* out = p.partial + (size_t)split * p.N * p.K;
+  const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + ni * 16 + l15;
+      const int k = k0 + wk * 64 + ki * 16 + 4 * g;
+      if (n < p.N && k < p.K) *(f32x4*)(out + (size_t)n * p.K + k) = acc[ki][ni];
+    }
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, long long n,
+                                       int splits, long long sstride, int accumulate) {
+  const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  if (i4 + 4 <= n) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < splits; ++k) s += *(const f32x4*)(partial + (size_t)k * sstride + i4);
+    if (accumulate) s += *(const f32x4*)(out + i4);
+    *(f32x4*)(out + i4) = s;
+  } else {
+    for (long long i = i4; i < n; ++i) {
+      float s = accumulate ? out[i] : 0.f;
+      for (int k = 0; k < splits; ++k) s += partial[(size_t)k * sstride + i];
+      out[i] = s;
+    }
+  }
+}
+
+// conv weight gradient: partial [splits][N][Kp] in tap-major order (k = tap*Cp + c) -> dW [N][Cin][k] (parameter layout)
+__global__ void unpack_conv_wgrad_kernel(const float* __restrict__ partial, float* __restrict__ dW, int splits, int N,
+                                         int Cin, int k, int Cp, int Kp) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)N * Cin * k) return;
+  const int tap = (int)(i % k);
+  const int c = (int)((i / k) % Cin);
+  const int n = (int)(i / ((long long)k * Cin));
+  float s = 0.f;
+  for (int sp = 0; sp < splits; ++sp) s += partial[((size_t)sp * N + n) * Kp + tap * Cp + c];
+  dW[i] = s;
+}
+
+// column sums of a [M, N] matrix: block b sums rows [b*rpb, (b+1)*rpb) -> partial[b, N]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ Y, RowMap y, int M, int N, int rpb,
+                                                     float* __restrict__ partial) {
+  __shared__ float red[8][1024 + 8];
+  const int tid = threadIdx.x, cl = tid & 31, rl = tid >> 5;
+  const int nch = N >> 3;
+  const int mbeg = blockIdx.x * rpb, mend = min(M, mbeg + rpb);
+  float acc[4][8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+  for (int m = mbeg + rl; m < mend; m += 8) {
+    const T* row = Y + row_off(y, m);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cl + 32 * j;
+      if (c < nch) {
+        float v[8];
+        load8(row + c * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] += v[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = cl + 32 * j;
+    if (c < nch)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[rl][c * 8 + e] = acc[j][e];
+  }
+  __syncthreads();
+  for (int n = tid; n < N; n += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += red[r][n];
+    partial[(size_t)blockIdx.x * N + n] = s;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static int launch_gemm_nt(const eg_gemm_desc* d, hipStream_t s) {
+  GemmNT<T> p;
+  p.A = (const T*)d->A; p.W = (const T*)d->W; p.C = (T*)d->C; p.bias = d->bias;
+  p.residual = (const T*)d->residual; p.gate = (const T*)d->gate; p.out_pre = (T*)d->out_pre; p.st = d->state;
+  p.a = to_rowmap(d->a); p.c = to_rowmap(d->c); p.r = to_rowmap(d->r); p.pm = to_rowmap(d->p);
+  p.M = d->M; p.N = d->N; p.K = d->K; p.ldw = d->ldw; p.act = d->act;
+  p.tiles_n = (d->N + BN - 1) / BN;
+  p.nblocks = p.tiles_n * ((d->M + BM - 1) / BM);
+  p.d1 = make_drop(d->drop1_p, d->drop1_site);
+  p.d2 = make_drop(d->drop2_p, d->drop2_site);
+  p.gate_scale = d->gate_scale == 0.f ? 1.0f : d->gate_scale;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3(p.nblocks), dim3(256), NT_LDS_BYTES, s, p);
+  EG_LAUNCH_CHECK("gemm_nt");
+  return 0;
+}
+
+extern "C" int eg_gemm_nt(const eg_gemm_desc* d, void* stream) {
+  EG_CHECK(d && d->A && d->W && d->C, "eg_gemm_nt: null operand");
+  EG_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "eg_gemm_nt: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+  EG_CHECK(d->dtype == EG_F32 || d->dtype == EG_BF16, "eg_gemm_nt: bad dtype %d", d->dtype);
+  const int bk = d->dtype == EG_BF16 ? 64 : 32;
+  const int al = d->dtype == EG_BF16 ? 8 : 4;  // elements per 16 B
+  EG_CHECK(d->K % bk == 0, "eg_gemm_nt: K=%d must be a multiple of %d", d->K, bk);
+  EG_CHECK(d->N % 8 == 0, "eg_gemm_nt: N=%d must be a multiple of 8", d->N);
+  EG_CHECK(d->ldw >= d->K && d->ldw % al == 0, "eg_gemm_nt: ldw=%d", d->ldw);
+  EG_CHECK(d->a.row_stride % al == 0 && d->a.group_stride % al == 0, "eg_gemm_nt: A rows must be 16-B aligned");
+  EG_CHECK(d->c.row_stride % 8 == 0 && d->c.group_stride % 8 == 0, "eg_gemm_nt: C rows must be 8-element aligned");
+  EG_CHECK(!d->residual || (d->r.row_stride % 8 == 0 && d->r.group_stride % 8 == 0), "eg_gemm_nt: residual rows");
+  EG_CHECK(!d->out_pre || (d->p.row_stride % 8 == 0 && d->p.group_stride % 8 == 0), "eg_gemm_nt: out_pre rows");
+  EG_CHECK((d->drop1_p == 0.f && d->drop2_p == 0.f) || d->state, "eg_gemm_nt: dropout needs a step state");
+  EG_CHECK(d->drop1_p >= 0.f && d->drop1_p < 1.f && d->drop2_p >= 0.f && d->drop2_p < 1.f, "eg_gemm_nt: dropout p");
+  EG_CHECK((long long)d->M * d->N < (1ll << 32), "eg_gemm_nt: M*N exceeds the 32-bit dropout index");
+  EG_CHECK(((uintptr_t)d->A | (uintptr_t)d->W | (uintptr_t)d->C) % 16 == 0, "eg_gemm_nt: operands must be 16-B aligned");
+  hipStream_t s = (hipStream_t)stream;
+  return d->dtype == EG_BF16 ? launch_gemm_nt<bf16_t>(d, s) : launch_gemm_nt<float>(d, s);
+}
+
+template <typename T>
+static int launch_gemm_tn(const eg_gemm_tn_desc* d, hipStream_t s) {
+  GemmTN<T> p;
+  p.dY = (const T*)d->dY; p.X = (const T*)d->X; p.partial = d->partial;
+  p.y = to_rowmap(d->y); p.x = to_rowmap(d->x);
+  p.M = d->M; p.N = d->N; p.K = d->K; p.splits = d->splits;
+  int rps = (d->M + d->splits - 1) / d->splits;
+  p.rows_per_split = (rps + 31) / 32 * 32;
+  p.tiles_k = (d->K + 127) / 128;
+  p.tiles_nk = p.tiles_k * ((d->N + 127) / 128);
+  const int lds = 4 * 32 * TNCfg<T>::ROWB;
+  hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(p.tiles_nk * d->splits), dim3(256), lds, s, p);
+  EG_LAUNCH_CHECK("gemm_tn");
+  return 0;
+}
+
+extern "C" int eg_gemm_tn(const eg_gemm_tn_desc* d, void* stream) {
+  EG_CHECK(d && d->dY && d->X && d->partial, "eg_gemm_tn: null operand");
+  EG_CHECK(d->M > 0 && d->N > 0 && d->K > 0 && d->splits > 0, "eg_gemm_tn: bad shape");
+  EG_CHECK(d->dtype == EG_F32 || d->dtype == EG_BF16, "eg_gemm_tn: bad dtype %d", d->dtype);
+  EG_CHECK(d->N % 8 == 0 && d->K % 8 == 0, "eg_gemm_tn: N=%d, K=%d must be multiples of 8", d->N, d->K);
+  const int al = d->dtype == EG_BF16 ? 8 : 4;
+  EG_CHECK(d->y.row_stride % al == 0 && d->y.group_stride % al == 0 && d->x.row_stride % al == 0 &&
+               d->x.group_stride % al == 0, "eg_gemm_tn: rows must be 16-B aligned");
+  EG_CHECK(((uintptr_t)d->dY | (uintptr_t)d->X | (uintptr_t)d->partial) % 16 == 0, "eg_gemm_tn: alignment");
+  hipStream_t s = (hipStream_t)stream;
+  return d->dtype == EG_BF16 ? launch_gemm_tn<bf16_t>(d, s) : launch_gemm_tn<float>(d, s);
+}
+
+extern "C" int eg_reduce_partials(const float* partial, float* out, int64_t n, int splits, int64_t split_stride,
+                                  int accumulate, void* stream) {
+  EG_CHECK(partial && out && n > 0 && splits > 0 && split_stride >= n, "eg_reduce_partials: bad arguments");
+  EG_CHECK(((uintptr_t)partial | (uintptr_t)out) % 16 == 0 && split_stride % 4 == 0,
+           "eg_reduce_partials: 16-B alignment (split_stride %% 4 == 0)");
+  const long long nthreads = (n + 3) / 4;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, partial, out, (long long)n, splits, (long long)split_stride, accumulate);
+  EG_LAUNCH_CHECK("reduce_partials");
+  return 0;
+}
+
+extern "C" int eg_unpack_conv_wgrad(const float* partial, float* dW, int splits, int N, int Cin, int k, int Cp, int Kp,
+                                    void* stream) {
+  EG_CHECK(partial && dW && splits > 0 && N > 0 && Cin > 0 && k > 0 && Cp >= Cin && Kp >= k * Cp,
+           "eg_unpack_conv_wgrad: bad arguments");
+  const long long n = (long long)N * Cin * k;
+  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     partial, dW, splits, N, Cin, k, Cp, Kp);
+  EG_LAUNCH_CHECK("unpack_conv_wgrad");
+  return 0;
+}
+
+extern "C" int eg_colsum(const void* Y, eg_rowmap y, int M, int N, float* partial, int nblk, int dtype,
+                         void* stream) {
+  EG_CHECK(Y && partial && M > 0 && N > 0 && nblk > 0, "eg_colsum: bad arguments");
+  EG_CHECK(N % 8 == 0 && N <= 1024, "eg_colsum: N=%d must be a multiple of 8 and <= 1024", N);
+  const int rpb = (M + nblk - 1) / nblk;
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Y,
+                       to_rowmap(y), M, N, rpb, partial);
+  else if (dtype == EG_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)Y,
+                       to_rowmap(y), M, N, rpb, partial);
+  else
+    return eg_fail("eg_colsum: bad dtype %d", dtype);
+  EG_LAUNCH_CHECK("colsum");
+  return 0;
+}

@@ -1,0 +1,388 @@
+// Small per-sample kernels around the encoder: sequence assembly (CLS / shared tokens), pooling +
+// symmetric fusion operands, the final class projection fused with cross-entropy, and their backward forms.
+// These touch [B, d]-sized data; they are latency-bound, so each is a single short launch.
+#include "common.h"
+
+namespace {
+
+// dst[b, off + r, :] = src[(b % src_nb), r, :] (+ pos[off + r, :])      src fp32 (parameters such as cls_token)
+template <typename T>
+__global__ void rows_bcast_f32_kernel(const float* __restrict__ src, const float* __restrict__ pos, T* __restrict__ dst,
+                                      int NB, int S, int D, int R, int off, int src_nb) {
+  const int b = blockIdx.y, r = blockIdx.x;
+  const float* s = src + ((size_t)(b % src_nb) * R + r) * D;
+  T* d = dst + ((size_t)b * S + off + r) * D;
+  for (int n = threadIdx.x; n < D; n += blockDim.x) {
+    float v = s[n];
+    if (pos) v += pos[(size_t)(off + r) * D + n];
+    Elem<T>::st(d + n, v);
+  }
+}
+
+// dst[b_dst0 + b, off + r, :] = src[b_src0 + b, off + r, :]   (copy the shared synchrony tokens to stream 2)
+template <typename T>
+__global__ void rows_copy_kernel(T* __restrict__ seq, int S, int D, int R, int off, int b_src0, int b_dst0) {
+  const int b = blockIdx.y, r = blockIdx.x;
+  const T* s = seq + ((size_t)(b_src0 + b) * S + off + r) * D;
+  T* d = seq + ((size_t)(b_dst0 + b) * S + off + r) * D;
+  for (int n = threadIdx.x; n < D; n += blockDim.x) d[n] = s[n];
+}
+
+// pooling + fusion operands (D:1193-1212, D:933-938, D:1222-1223)
+//   z [2B, S, D]; stream 1 = samples [0,B), stream 2 = [B,2B)
+//   cls1/cls2 fp32 [B,D]; comb [B,3D] = [a+b, a*b, |a-b|]; zf[:, D:2D] = mean_{s>=off} z1, zf[:, 2D:3D] = same for z2
+//   ibs_pool fp32+T [B,D] = mean_{1<=s<1+n_ibs} z1   (n_ibs may be 0)
+template <typename T>
+__global__ void pool_fuse_fwd_kernel(const T* __restrict__ z, float* __restrict__ cls1, float* __restrict__ cls2,
+                                     T* __restrict__ comb, T* __restrict__ zf, float* __restrict__ ibs_pool_f,
+                                     T* __restrict__ ibs_pool, int B, int S, int D, int off, int n_ibs, int ibs_first) {
+  const int b = blockIdx.x;
+  const T* z1 = z + (size_t)b * S * D;
+  const T* z2 = z + (size_t)(b + B) * S * D;
+  for (int n = threadIdx.x; n < D; n += blockDim.x) {
+    const float a = Elem<T>::ld(z1 + n), c = Elem<T>::ld(z2 + n);
+    cls1[(size_t)b * D + n] = a;
+    cls2[(size_t)b * D + n] = c;
+    Elem<T>::st(comb + (size_t)b * 3 * D + n, a + c);
+    Elem<T>::st(comb + (size_t)b * 3 * D + D + n, a * c);
+    Elem<T>::st(comb + (size_t)b * 3 * D + 2 * D + n, fabsf(a - c));
+    float m1 = 0.f, m2 = 0.f;
+    for (int s = off; s < S; ++s) {
+      m1 += Elem<T>::ld(z1 + (size_t)s * D + n);
+      m2 += Elem<T>::ld(z2 + (size_t)s * D + n);
+    }
+    const float inv = 1.0f / (float)(S - off);
+    Elem<T>::st(zf + (size_t)b * 3 * D + D + n, m1 * inv);
+    Elem<T>::st(zf + (size_t)b * 3 * D + 2 * D + n, m2 * inv);
+    if (n_ibs > 0) {
+      float mi = 0.f;
+      for (int s = ibs_first; s < ibs_first + n_ibs; ++s) mi += Elem<T>::ld(z1 + (size_t)s * D + n);
+      mi /= (float)n_ibs;
+      ibs_pool_f[(size_t)b * D + n] = mi;
+      Elem<T>::st(ibs_pool + (size_t)b * D + n, mi);
+    }
+  }
+}
+
+// backward of the above: writes the full dz [2B, S, D] (zeros where nothing flows)
+template <typename T>
+__global__ void pool_fuse_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dcomb, const T* __restrict__ dzf,
+                                     const float* __restrict__ gcls1, const float* __restrict__ gcls2,
+                                     const T* __restrict__ dibs_pool, const float* __restrict__ gibs_pool,
+                                     T* __restrict__ dz, int B, int S, int D, int off, int n_ibs, int ibs_first) {
+  const int b = blockIdx.x;
+  const T* z1 = z + (size_t)b * S * D;
+  const T* z2 = z + (size_t)(b + B) * S * D;
+  T* d1 = dz + (size_t)b * S * D;
+  T* d2 = dz + (size_t)(b + B) * S * D;
+  const float invp = 1.0f / (float)(S - off);
+  for (int n = threadIdx.x; n < D; n += blockDim.x) {
+    const float a = Elem<T>::ld(z1 + n), c = Elem<T>::ld(z2 + n);
+    const float g0 = Elem<T>::ld(dcomb + (size_t)b * 3 * D + n);
+    const float g1 = Elem<T>::ld(dcomb + (size_t)b * 3 * D + D + n);
+    const float g2 = Elem<T>::ld(dcomb + (size_t)b * 3 * D + 2 * D + n);
+    const float sg = (a > c) ? 1.f : ((a < c) ? -1.f : 0.f);
+    float da = g0 + g1 * c + g2 * sg;
+    float dc = g0 + g1 * a - g2 * sg;
+    if (gcls1) da += gcls1[(size_t)b * D + n];
+    if (gcls2) dc += gcls2[(size_t)b * D + n];
+    const float dm1 = Elem<T>::ld(dzf + (size_t)b * 3 * D + D + n) * invp;
+    const float dm2 = Elem<T>::ld(dzf + (size_t)b * 3 * D + 2 * D + n) * invp;
+    float di = 0.f;
+    if (n_ibs > 0) {
+      if (dibs_pool) di += Elem<T>::ld(dibs_pool + (size_t)b * D + n);
+      if (gibs_pool) di += gibs_pool[(size_t)b * D + n];
+      di /= (float)n_ibs;
+    }
+    for (int s = 0; s < S; ++s) {
+      float v1 = 0.f, v2 = 0.f;
+      if (s == 0) { v1 = da; v2 = dc; }
+      if (s >= off) { v1 += dm1; v2 += dm2; }
+      if (n_ibs > 0 && s >= ibs_first && s < ibs_first + n_ibs) v1 += di;
+      Elem<T>::st(d1 + (size_t)s * D + n, v1);
+      Elem<T>::st(d2 + (size_t)s * D + n, v2);
+    }
+  }
+}
+
+// logits = h W^T + b  (ncls <= 16), per-sample CE; one wave per sample (D:1104-1105 / 1078 + D:1244 / 1250)
+template <typename T>
+__global__ __launch_bounds__(256) void classifier_ce_fwd_kernel(const T* __restrict__ h, const float* __restrict__ W,
+                                                                const float* __restrict__ bias,
+                                                                const long long* __restrict__ labels,
+                                                                float* __restrict__ logits, float* __restrict__ sample_loss,
+                                                                int B, int K, int ncls) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float lg[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) lg[c] = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float x = Elem<T>::ld(h + (size_t)b * K + k);
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < ncls) lg[c] += x * W[(size_t)c * K + k];
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+    if (c < ncls) {
+      lg[c] = wave_sum(lg[c]) + bias[c];
+      mx = fmaxf(mx, lg[c]);
+    }
+  if (lane == 0) {
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < ncls) {
+        logits[(size_t)b * ncls + c] = lg[c];
+        se += expf(lg[c] - mx);
+      }
+    if (labels && sample_loss) {
+      const int y = (int)labels[b];
+      float ly = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c == y) ly = lg[c];
+      sample_loss[b] = (mx + logf(se)) - ly;
+    }
+  }
+}
+
+__global__ void mean_kernel(const float* __restrict__ v, float* __restrict__ out, int n) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = red[0] / (float)n;
+}
+
+// dlogits[b,c] = gloss * (softmax - onehot)/B + glogits[b,c];  dh[b,k] = (sum_c dlogits[b,c] W[c,k]) * gate(h>0)*gate_scale
+template <typename T>
+__global__ __launch_bounds__(256) void classifier_ce_bwd_kernel(const T* __restrict__ h, const float* __restrict__ W,
+                                                                const float* __restrict__ logits,
+                                                                const long long* __restrict__ labels,
+                                                                const float* __restrict__ gloss,
+                                                                const float* __restrict__ glogits,
+                                                                float* __restrict__ dlogits, T* __restrict__ dh, int B,
+                                                                int K, int ncls, int use_gate, float gate_scale) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float dl[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    dl[c] = 0.f;
+    if (c < ncls) mx = fmaxf(mx, logits[(size_t)b * ncls + c]);
+  }
+  float se = 0.f;
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+    if (c < ncls) {
+      dl[c] = expf(logits[(size_t)b * ncls + c] - mx);
+      se += dl[c];
+    }
+  const float gl = (gloss && labels) ? *gloss / (float)B : 0.f;
+  const int y = labels ? (int)labels[b] : -1;
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+    if (c < ncls) {
+      float d = gl * (dl[c] / se - (c == y ? 1.f : 0.f));
+      if (glogits) d += glogits[(size_t)b * ncls + c];
+      dl[c] = d;
+      if (lane == 0) dlogits[(size_t)b * ncls + c] = d;
+    }
+  for (int k = lane; k < K; k += 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < ncls) s += dl[c] * W[(size_t)c * K + k];
+    if (use_gate) s = Elem<T>::ld(h + (size_t)b * K + k) > 0.f ? s * gate_scale : 0.f;
+    Elem<T>::st(dh + (size_t)b * K + k, s);
+  }
+}
+
+// dW[c,k] = sum_b dlogits[b,c] h[b,k];  db[c] = sum_b dlogits[b,c]      grid = ncls blocks
+template <typename T>
+__global__ void classifier_wgrad_kernel(const T* __restrict__ h, const float* __restrict__ dlogits,
+                                        float* __restrict__ dW, float* __restrict__ db, int B, int K, int ncls) {
+  const int c = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dlogits[(size_t)b * ncls + c] * Elem<T>::ld(h + (size_t)b * K + k);
+    dW[(size_t)c * K + k] = s;
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dlogits[(size_t)b * ncls + c];
+    db[c] = s;
+  }
+}
+
+// out[s, :] = sum_b dseq[b, s, :]  (position-embedding gradient; row 0 is also the cls_token gradient)
+template <typename T>
+__global__ void batch_rowsum_kernel(const T* __restrict__ dseq, float* __restrict__ out, int NB, int S, int D) {
+  const int s = blockIdx.x;
+  for (int n = threadIdx.x; n < D; n += blockDim.x) {
+    float a = 0.f;
+    for (int b = 0; b < NB; ++b) a += Elem<T>::ld(dseq + ((size_t)b * S + s) * D + n);
+    out[(size_t)s * D + n] = a;
+  }
+}
+
+// dst[b, r, :] = (src[b, off+r, :] (+ src[b+B2, off+r, :])) * (gate[b, r, :] > 0 ? gate_scale : 0)
+//   dst rows are addressed by a rowmap (e.g. the zero-padded dY buffer of the strided-conv backward)
+template <typename T>
+__global__ void rows_gather_gate_kernel(const T* __restrict__ src, const T* __restrict__ gate, T* __restrict__ dst,
+                                        RowMap dmap, int S, int D, int R, int off, int pair_shift, float gate_scale) {
+  const int b = blockIdx.y, r = blockIdx.x;
+  const T* s = src + ((size_t)b * S + off + r) * D;
+  const T* s2 = pair_shift ? src + ((size_t)(b + pair_shift) * S + off + r) * D : nullptr;
+  const T* gt = gate ? gate + ((size_t)b * R + r) * D : nullptr;
+  T* d = dst + row_off(dmap, b * R + r);
+  for (int n = threadIdx.x * 4; n < D; n += blockDim.x * 4) {
+    float v[4];
+    load4(s + n, v);
+    if (s2) {
+      float w[4];
+      load4(s2 + n, w);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += w[e];
+    }
+    if (gt) {
+      float gv[4];
+      load4(gt + n, gv);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gv[e] > 0.f ? v[e] * gate_scale : 0.f;
+    }
+    store4(d + n, v);
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32, who)          \
+  if ((dtype) == EG_BF16) { CALL_BF16; }                      \
+  else if ((dtype) == EG_F32) { CALL_F32; }                   \
+  else return eg_fail("%s: bad dtype %d", who, (int)(dtype));
+
+extern "C" int eg_rows_bcast_f32(const float* src, const float* pos, void* seq, int NB, int S, int D, int R, int off,
+                                 int src_nb, int dtype, void* stream) {
+  EG_CHECK(src && seq && NB > 0 && R > 0 && off >= 0 && off + R <= S && src_nb > 0, "eg_rows_bcast_f32: bad arguments");
+  dim3 grid(R, NB);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(rows_bcast_f32_kernel<bf16_t>, grid, dim3(256), 0, s, src, pos, (bf16_t*)seq, NB, S, D, R, off, src_nb),
+             hipLaunchKernelGGL(rows_bcast_f32_kernel<float>, grid, dim3(256), 0, s, src, pos, (float*)seq, NB, S, D, R, off, src_nb),
+             "eg_rows_bcast_f32");
+  EG_LAUNCH_CHECK("rows_bcast_f32");
+  return 0;
+}
+
+extern "C" int eg_rows_copy(void* seq, int S, int D, int R, int off, int b_src0, int b_dst0, int nb, int dtype,
+                            void* stream) {
+  EG_CHECK(seq && nb > 0 && R > 0 && off >= 0 && off + R <= S, "eg_rows_copy: bad arguments");
+  dim3 grid(R, nb);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(rows_copy_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)seq, S, D, R, off, b_src0, b_dst0),
+             hipLaunchKernelGGL(rows_copy_kernel<float>, grid, dim3(256), 0, s, (float*)seq, S, D, R, off, b_src0, b_dst0),
+             "eg_rows_copy");
+  EG_LAUNCH_CHECK("rows_copy");
+  return 0;
+}
+
+extern "C" int eg_pool_fuse_fwd(const void* z, float* cls1, float* cls2, void* comb, void* zf, float* ibs_pool_f,
+                                void* ibs_pool, int B, int S, int D, int off, int n_ibs, int ibs_first, int dtype,
+                                void* stream) {
+  EG_CHECK(z && cls1 && cls2 && comb && zf, "eg_pool_fuse_fwd: null pointer");
+  EG_CHECK(B > 0 && off > 0 && off < S, "eg_pool_fuse_fwd: bad shape");
+  EG_CHECK(n_ibs == 0 || (ibs_pool_f && ibs_pool && ibs_first >= 1 && ibs_first + n_ibs <= S), "eg_pool_fuse_fwd: ibs range");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(pool_fuse_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)z, cls1, cls2, (bf16_t*)comb, (bf16_t*)zf, ibs_pool_f, (bf16_t*)ibs_pool, B, S, D, off, n_ibs, ibs_first),
+             hipLaunchKernelGGL(pool_fuse_fwd_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)z, cls1, cls2, (float*)comb, (float*)zf, ibs_pool_f, (float*)ibs_pool, B, S, D, off, n_ibs, ibs_first),
+             "eg_pool_fuse_fwd");
+  EG_LAUNCH_CHECK("pool_fuse_fwd");
+  return 0;
+}
+
+extern "C" int eg_pool_fuse_bwd(const void* z, const void* dcomb, const void* dzf, const float* gcls1, const float* gcls2,
+                                const void* dibs_pool, const float* gibs_pool, void* dz, int B, int S, int D, int off,
+                                int n_ibs, int ibs_first, int dtype, void* stream) {
+  EG_CHECK(z && dcomb && dzf && dz, "eg_pool_fuse_bwd: null pointer");
+  EG_CHECK(B > 0 && off > 0 && off < S, "eg_pool_fuse_bwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(pool_fuse_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)z, (const bf16_t*)dcomb, (const bf16_t*)dzf, gcls1, gcls2, (const bf16_t*)dibs_pool, gibs_pool, (bf16_t*)dz, B, S, D, off, n_ibs, ibs_first),
+             hipLaunchKernelGGL(pool_fuse_bwd_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)z, (const float*)dcomb, (const float*)dzf, gcls1, gcls2, (const float*)dibs_pool, gibs_pool, (float*)dz, B, S, D, off, n_ibs, ibs_first),
+             "eg_pool_fuse_bwd");
+  EG_LAUNCH_CHECK("pool_fuse_bwd");
+  return 0;
+}
+
+extern "C" int eg_classifier_ce_fwd(const void* h, const float* W, const float* bias, const int64_t* labels,
+                                    float* logits, float* sample_loss, float* loss, int B, int K, int ncls, int dtype,
+                                    void* stream) {
+  EG_CHECK(h && W && bias && logits, "eg_classifier_ce_fwd: null pointer");
+  EG_CHECK(B > 0 && K > 0 && ncls > 0 && ncls <= 16, "eg_classifier_ce_fwd: ncls=%d must be in [1,16]", ncls);
+  EG_CHECK(!labels || (sample_loss && loss), "eg_classifier_ce_fwd: labels need sample_loss and loss outputs");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((B + 3) / 4);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(classifier_ce_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)h, W, bias, (const long long*)labels, logits, sample_loss, B, K, ncls),
+             hipLaunchKernelGGL(classifier_ce_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)h, W, bias, (const long long*)labels, logits, sample_loss, B, K, ncls),
+             "eg_classifier_ce_fwd");
+  if (labels) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, sample_loss, loss, B);
+  EG_LAUNCH_CHECK("classifier_ce_fwd");
+  return 0;
+}
+
+extern "C" int eg_classifier_ce_bwd(const void* h, const float* W, const float* logits, const int64_t* labels,
+                                    const float* gloss, const float* glogits, float* dlogits, void* dh, float* dW,
+                                    float* db, int B, int K, int ncls, int use_gate, float gate_scale, int dtype,
+                                    void* stream) {
+  EG_CHECK(h && W && logits && dlogits && dh && dW && db, "eg_classifier_ce_bwd: null pointer");
+  EG_CHECK(B > 0 && K > 0 && ncls > 0 && ncls <= 16, "eg_classifier_ce_bwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((B + 3) / 4);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(classifier_ce_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)h, W, logits, (const long long*)labels, gloss, glogits, dlogits, (bf16_t*)dh, B, K, ncls, use_gate, gate_scale);
+             hipLaunchKernelGGL(classifier_wgrad_kernel<bf16_t>, dim3(ncls), dim3(256), 0, s, (const bf16_t*)h, dlogits, dW, db, B, K, ncls),
+             hipLaunchKernelGGL(classifier_ce_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)h, W, logits, (const long long*)labels, gloss, glogits, dlogits, (float*)dh, B, K, ncls, use_gate, gate_scale);
+             hipLaunchKernelGGL(classifier_wgrad_kernel<float>, dim3(ncls), dim3(256), 0, s, (const float*)h, dlogits, dW, db, B, K, ncls),
+             "eg_classifier_ce_bwd");
+  EG_LAUNCH_CHECK("classifier_ce_bwd");
+  return 0;
+}
+
+extern "C" int eg_batch_rowsum(const void* dseq, float* out, int NB, int S, int D, int rows, int dtype, void* stream) {
+  EG_CHECK(dseq && out && NB > 0 && rows > 0 && rows <= S, "eg_batch_rowsum: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(batch_rowsum_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)dseq, out, NB, S, D),
+             hipLaunchKernelGGL(batch_rowsum_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)dseq, out, NB, S, D),
+             "eg_batch_rowsum");
+  EG_LAUNCH_CHECK("batch_rowsum");
+  return 0;
+}
+
+extern "C" int eg_rows_gather_gate(const void* src, const void* gate, void* dst, eg_rowmap dmap, int nb, int S, int D,
+                                   int R, int off, int pair_shift, float gate_scale, int dtype, void* stream) {
+  EG_CHECK(src && dst && nb > 0 && R > 0 && off >= 0 && off + R <= S && D % 4 == 0, "eg_rows_gather_gate: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(R, nb);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(rows_gather_gate_kernel<bf16_t>, grid, dim3(64), 0, s, (const bf16_t*)src, (const bf16_t*)gate, (bf16_t*)dst, to_rowmap(dmap), S, D, R, off, pair_shift, gate_scale),
+             hipLaunchKernelGGL(rows_gather_gate_kernel<float>, grid, dim3(64), 0, s, (const float*)src, (const float*)gate, (float*)dst, to_rowmap(dmap), S, D, R, off, pair_shift, gate_scale),
+             "eg_rows_gather_gate");
+  EG_LAUNCH_CHECK("rows_gather_gate");
+  return 0;
+}

@@ -1,0 +1,180 @@
+// LayerNorm(eps = 1e-5) forward / backward, one wave per row, fp32 statistics.  HBM-bound.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAXCH = 4;  // lane owns chunks lane + 64*j of 4 elements => D <= 1024
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ stats, int M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = D >> 2;
+  float v[LN_MAXCH][4];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXCH; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nch) {
+      load4(x + (size_t)row * D + c * 4, v[j]);
+      s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+    }
+  }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXCH; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nch)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[j][e] - mean;
+        q += d * d;
+      }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / D + 1e-5f);
+#pragma unroll
+  for (int j = 0; j < LN_MAXCH; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nch) {
+      float g[4], b[4], o[4];
+      load4(gamma + c * 4, g);
+      load4(beta + c * 4, b);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * g[e] + b[e];
+      store4(y + (size_t)row * D + c * 4, o);
+    }
+  }
+  if (stats && lane == 0) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rstd;
+  }
+}
+
+// each wave walks rows wave_id, wave_id + nwaves, ...; dgamma/dbeta accumulate in registers and are
+// reduced per block into partial[blk][0][D] (dgamma) and partial[blk][1][D] (dbeta)
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, T* __restrict__ dx,
+                                                            T* __restrict__ dx_drop, float* __restrict__ partial, int M,
+                                                            int D, DropCfg d1, DropCfg d2, const eg_step_state* st) {
+  __shared__ float red[4][2][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D >> 2;
+  float g[LN_MAXCH][4], dg[LN_MAXCH][4], db[LN_MAXCH][4];
+#pragma unroll
+  for (int j = 0; j < LN_MAXCH; ++j) {
+    const int c = lane + 64 * j;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { g[j][e] = 0.f; dg[j][e] = 0.f; db[j][e] = 0.f; }
+    if (c < nch) load4(gamma + c * 4, g[j]);
+  }
+  uint32_t seed_lo = 0, seed_hi = 0;
+  const bool drop = (d1.thresh | d2.thresh) != 0 && dx_drop != nullptr;
+  if (drop) { seed_lo = st->seed_lo; seed_hi = st->seed_hi; }
+  const int nwaves = gridDim.x * 4;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += nwaves) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float xh[LN_MAXCH][4], dv[LN_MAXCH][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nch) {
+        float xv[4];
+        load4(x + (size_t)row * D + c * 4, xv);
+        load4(dy + (size_t)row * D + c * 4, dv[j]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[j][e] = (xv[e] - mean) * rstd;
+          dg[j][e] += dv[j][e] * xh[j][e];
+          db[j][e] += dv[j][e];
+          const float dxh = dv[j][e] * g[j][e];
+          s1 += dxh;
+          s2 += dxh * xh[j][e];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int j = 0; j < LN_MAXCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nch) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (dv[j][e] * g[j][e] - c1 - xh[j][e] * c2);
+        store4(dx + (size_t)row * D + c * 4, o);
+        if (dx_drop) {
+          if (drop) {
+            const uint32_t idx = (uint32_t)row * (uint32_t)D + (uint32_t)(c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o[e] = eg_dropout(o[e], d1, seed_lo, seed_hi, idx + e);
+              o[e] = eg_dropout(o[e], d2, seed_lo, seed_hi, idx + e);
+            }
+          }
+          store4(dx_drop + (size_t)row * D + c * 4, o);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < LN_MAXCH; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nch)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[wave][0][c * 4 + e] = dg[j][e];
+        red[wave][1][c * 4 + e] = db[j][e];
+      }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    const int which = i / D, n = i % D;
+    partial[(size_t)blockIdx.x * 2 * D + i] = red[0][which][n] + red[1][which][n] + red[2][which][n] + red[3][which][n];
+  }
+}
+
+}  // namespace
+
+extern "C" int eg_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int D,
+                                int dtype, void* stream) {
+  EG_CHECK(x && gamma && beta && y, "eg_layernorm_fwd: null pointer");
+  EG_CHECK(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "eg_layernorm_fwd: D=%d must be a multiple of 4, <= 1024", D);
+  dim3 grid((M + 3) / 4);
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma,
+                       beta, (bf16_t*)y, stats, M, D);
+  else if (dtype == EG_F32)
+    hipLaunchKernelGGL(layernorm_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma, beta,
+                       (float*)y, stats, M, D);
+  else
+    return eg_fail("eg_layernorm_fwd: bad dtype %d", dtype);
+  EG_LAUNCH_CHECK("layernorm_fwd");
+  return 0;
+}
+
+extern "C" int eg_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                                void* dx_drop, float* partial, int nblk, int M, int D, int dtype, float drop1_p,
+                                uint32_t drop1_site, float drop2_p, uint32_t drop2_site, const eg_step_state* state,
+                                void* stream) {
+  EG_CHECK(dy && x && stats && gamma && dx && partial, "eg_layernorm_bwd: null pointer");
+  EG_CHECK(M > 0 && D > 0 && D % 4 == 0 && D <= 1024 && nblk > 0, "eg_layernorm_bwd: bad shape");
+  EG_CHECK((drop1_p == 0.f && drop2_p == 0.f) || state, "eg_layernorm_bwd: dropout needs a step state");
+  EG_CHECK((long long)M * D < (1ll << 32), "eg_layernorm_bwd: M*D exceeds the 32-bit dropout index");
+  DropCfg d1 = make_drop(drop1_p, drop1_site), d2 = make_drop(drop2_p, drop2_site);
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                       (const bf16_t*)x, stats, gamma, (bf16_t*)dx, (bf16_t*)dx_drop, partial, M, D, d1, d2, state);
+  else if (dtype == EG_F32)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
+                       (const float*)x, stats, gamma, (float*)dx, (float*)dx_drop, partial, M, D, d1, d2, state);
+  else
+    return eg_fail("eg_layernorm_bwd: bad dtype %d", dtype);
+  EG_LAUNCH_CHECK("layernorm_bwd");
+  return 0;
+}

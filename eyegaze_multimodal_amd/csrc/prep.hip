@@ -1,0 +1,199 @@
+// Staging kernels: input windows [B,C,T] -> channel-last padded rows, fp32 master parameters -> compute-dtype
+// copies in the layouts the GEMMs read.  All HBM-bound, coalesced on both sides via an LDS transpose.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+thread_local char eg_err_buf[512] = {0};
+int eg_fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(eg_err_buf, sizeof(eg_err_buf), fmt, ap);
+  va_end(ap);
+  return 1;
+}
+extern "C" const char* eg_last_error(void) { return eg_err_buf; }
+extern "C" int eg_abi_version(void) { return EG_ABI_VERSION; }
+extern "C" int eg_device_info(int* cu_count, char* arch, int arch_len) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+    return eg_fail("eg_device_info: no HIP device");
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", prop.gcnArchName);
+  return 0;
+}
+
+namespace {
+
+// x [NB, C, T] f32 -> xt [NB, Tp, Cp]; one block = 256 consecutive padded time steps of one window
+template <typename T>
+__global__ __launch_bounds__(256) void window_pack_kernel(const float* __restrict__ x, T* __restrict__ xt, int C, int Tn,
+                                                          int Cp, int pad_front, int Tp) {
+  extern __shared__ float tile[];  // [256][Cp + 1]
+  const int nb = blockIdx.y, tp0 = blockIdx.x * 256, tid = threadIdx.x;
+  const int pitch = Cp + 1;
+  const int t = tp0 + tid - pad_front;
+  const bool tv = t >= 0 && t < Tn && tp0 + tid < Tp;
+  const float* xb = x + (size_t)nb * C * Tn;
+  for (int c = 0; c < Cp; ++c) tile[tid * pitch + c] = (tv && c < C) ? xb[(size_t)c * Tn + t] : 0.f;
+  __syncthreads();
+  const int rows = min(256, Tp - tp0);
+  const int nchunk = rows * Cp / 8;
+  T* ob = xt + ((size_t)nb * Tp + tp0) * Cp;
+  for (int ch = tid; ch < nchunk; ch += 256) {
+    const int e = ch * 8, r = e / Cp, c = e % Cp;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tile[r * pitch + c + j];
+    store8(ob + e, v);
+  }
+}
+
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long long n) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 4 <= n) {
+    float v[4];
+    load4(src + i, v);
+    store4(dst + i, v);
+  } else {
+    for (long long j = i; j < n; ++j) Elem<T>::st(dst + j, src[j]);
+  }
+}
+
+// src [R, Cc] -> dst[c * ldd + r]
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int R,
+                                                             int Cc, int ldd) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < Cc) ? src[(size_t)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < Cc && r < R) Elem<T>::st(dst + (size_t)c * ldd + r, tile[tx][i]);
+  }
+}
+
+// w [N, Cin, k] -> dst [N, Kp]: dst[n][tap*Cp + c] = w[n][c][tap]
+template <typename T>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int N, int Cin, int k, int Cp,
+                                        int Kp) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)N * Kp) return;
+  const int n = (int)(i / Kp), kk = (int)(i % Kp);
+  const int tap = kk / Cp, c = kk % Cp;
+  const float v = (tap < k && c < Cin) ? w[((size_t)n * Cin + c) * k + tap] : 0.f;
+  Elem<T>::st(dst + i, v);
+}
+
+// backward-data weights: dst[p][c][j*N + n] = w[n][c][s*(J-1-j) + p]   (0 when the tap index exceeds k-1)
+template <typename T>
+__global__ void pack_convT_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int N, int Cin, int k, int s,
+                                         int J) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long per_phase = (long long)Cin * J * N;
+  if (i >= per_phase * s) return;
+  const int p = (int)(i / per_phase);
+  const long long rem = i % per_phase;
+  const int c = (int)(rem / (J * N));
+  const int jn = (int)(rem % (J * N));
+  const int j = jn / N, n = jn % N;
+  const int tap = s * (J - 1 - j) + p;
+  const float v = tap < k ? w[((size_t)n * Cin + c) * k + tap] : 0.f;
+  Elem<T>::st(dst + i, v);
+}
+
+}  // namespace
+
+extern "C" int eg_window_pack(const float* x, void* xt, int NB, int C, int T, int Cp, int pad_front, int Tp, int dtype,
+                              void* stream) {
+  EG_CHECK(x && xt, "eg_window_pack: null pointer");
+  EG_CHECK(NB > 0 && C > 0 && T > 0, "eg_window_pack: bad shape NB=%d C=%d T=%d", NB, C, T);
+  EG_CHECK(Cp >= C && Cp % 8 == 0 && Cp <= 256, "eg_window_pack: Cp=%d must be a multiple of 8 in [C, 256]", Cp);
+  EG_CHECK(pad_front >= 0 && Tp >= T + pad_front, "eg_window_pack: Tp=%d < T+pad_front", Tp);
+  dim3 grid((Tp + 255) / 256, NB);
+  const size_t lds = 256 * (Cp + 1) * sizeof(float);
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(window_pack_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, x, (bf16_t*)xt, C, T, Cp,
+                       pad_front, Tp);
+  else if (dtype == EG_F32)
+    hipLaunchKernelGGL(window_pack_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, x, (float*)xt, C, T, Cp,
+                       pad_front, Tp);
+  else
+    return eg_fail("eg_window_pack: bad dtype %d", dtype);
+  EG_LAUNCH_CHECK("window_pack");
+  return 0;
+}
+
+extern "C" int eg_cast(const float* src, void* dst, int64_t n, int dtype, void* stream) {
+  EG_CHECK(src && dst && n > 0, "eg_cast: bad arguments");
+  EG_CHECK(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 8 == 0), "eg_cast: alignment");
+  const long long nt = (n + 3) / 4;
+  dim3 grid((unsigned)((nt + 255) / 256));
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(cast_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (long long)n);
+  else if (dtype == EG_F32)
+    hipLaunchKernelGGL(cast_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, (long long)n);
+  else
+    return eg_fail("eg_cast: bad dtype %d", dtype);
+  EG_LAUNCH_CHECK("cast");
+  return 0;
+}
+
+extern "C" int eg_transpose_cast(const float* src, void* dst, int R, int Cc, int ldd, int dtype, void* stream) {
+  EG_CHECK(src && dst && R > 0 && Cc > 0 && ldd >= R, "eg_transpose_cast: bad arguments");
+  dim3 grid((Cc + 31) / 32, (R + 31) / 32);
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, R, Cc,
+                       ldd);
+  else if (dtype == EG_F32)
+    hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, R, Cc,
+                       ldd);
+  else
+    return eg_fail("eg_transpose_cast: bad dtype %d", dtype);
+  EG_LAUNCH_CHECK("transpose_cast");
+  return 0;
+}
+
+extern "C" int eg_pack_conv_weight(const float* w, void* dst, int N, int Cin, int k, int Cp, int Kp, int dtype,
+                                   void* stream) {
+  EG_CHECK(w && dst && N > 0 && Cin > 0 && k > 0, "eg_pack_conv_weight: bad arguments");
+  EG_CHECK(Cp >= Cin && Kp >= k * Cp, "eg_pack_conv_weight: Cp=%d Kp=%d too small", Cp, Kp);
+  const long long n = (long long)N * Kp;
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst, N, Cin,
+                       k, Cp, Kp);
+  else if (dtype == EG_F32)
+    hipLaunchKernelGGL(pack_conv_weight_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, w, (float*)dst, N, Cin, k,
+                       Cp, Kp);
+  else
+    return eg_fail("eg_pack_conv_weight: bad dtype %d", dtype);
+  EG_LAUNCH_CHECK("pack_conv_weight");
+  return 0;
+}
+
+extern "C" int eg_pack_convT_weight(const float* w, void* dst, int N, int Cin, int k, int stride, int dtype,
+                                    void* stream) {
+  EG_CHECK(w && dst && N > 0 && Cin > 0 && k > 0 && stride > 0, "eg_pack_convT_weight: bad arguments");
+  const int J = (k + stride - 1) / stride;
+  const long long n = (long long)stride * Cin * J * N;
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(pack_convT_weight_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst, N,
+                       Cin, k, stride, J);
+  else if (dtype == EG_F32)
+    hipLaunchKernelGGL(pack_convT_weight_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, w, (float*)dst, N, Cin,
+                       k, stride, J);
+  else
+    return eg_fail("eg_pack_convT_weight: bad dtype %d", dtype);
+  EG_LAUNCH_CHECK("pack_convT_weight");
+  return 0;
+}

@@ -1,0 +1,565 @@
+"""Step engine: sequences the C-ABI kernels (include/eyegaze_hip.h) for one forward / backward / optimiser
+step of the dual-stream window classifier.  torch is used for device memory, streams and (in ddp.py)
+torch.distributed only; every arithmetic op on the path is a HIP kernel from libeyegaze_hip.so.
+
+Data layout in HBM (NB = 2B windows: stream 1 = samples [0,B), stream 2 = [B,2B); M = NB*S token rows):
+  xt      [NB, Tp, Cp]      channel-last, zero-padded input windows (k//2 in front)           compute dtype
+  h0pad   [NB, R0, d]       conv-0 output, k//2 zero rows in front/behind (R0 = U*stride)      compute dtype
+  seq/x_l [M, d]            token rows [CLS | IBS | spec | temporal], row-major                compute dtype
+  qkv_l   [M, 3d]  ctx_l [M, d]  r1/r2 (pre-LN sums) [M, d]  hff_l [M, d_ff]                   compute dtype
+  lse_l   [NB, H, S]  LN stats [M, 2]  logits / losses                                          fp32
+  parameters, gradients, AdamW moments: ONE flat fp32 buffer each (16-B aligned segments, registration order)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import EG_BF16, EG_F32, GemmDesc, GemmTNDesc, StepState, call, ptr, rowmap
+
+# dropout site ids (any fixed numbering works: the mask depends on (seed, site, element index))
+SITE_CONV0, SITE_CONV1, SITE_SPEC, SITE_IBSTOK, SITE_IBSGEN, SITE_CLS, SITE_IBSCLS = 1, 2, 3, 4, 5, 6, 7
+
+
+def _layer_sites(l: int):
+    b = 16 + 8 * l
+    return dict(attn=b, drop1=b + 1, ffn_a=b + 2, ffn_b=b + 3, drop2=b + 4)
+
+
+def _align(n: int, a: int) -> int:
+    return (n + a - 1) // a * a
+
+
+class FlatParams:
+    """All parameters of a module as views of one flat fp32 buffer (+ a flat gradient buffer).
+    Segment offsets are multiples of 4 floats so every kernel can use 16-B accesses."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.module = module
+        self.names: List[str] = []
+        self.params: List[torch.nn.Parameter] = []
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        for n, p in module.named_parameters():
+            self.names.append(n)
+            self.params.append(p)
+            self.offsets[n] = off
+            off += _align(p.numel(), 4)
+        self.total = off
+        self.flat: Optional[torch.Tensor] = None
+        self.grad: Optional[torch.Tensor] = None
+
+    def ensure(self, device: torch.device):
+        """(Re)flattens when the module was moved / re-created since the last call."""
+        ok = self.flat is not None and self.flat.device == device
+        if ok:
+            base = self.flat.data_ptr()
+            for n, p in zip(self.names, self.params):
+                if p.data_ptr() != base + 4 * self.offsets[n] or p.dtype != torch.float32:
+                    ok = False
+                    break
+        if ok:
+            return
+        flat = torch.zeros(self.total, device=device, dtype=torch.float32)
+        for n, p in zip(self.names, self.params):
+            o = self.offsets[n]
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1).to(device=device, dtype=torch.float32))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+        self.flat = flat
+        self.grad = torch.zeros(self.total, device=device, dtype=torch.float32)
+
+    def p_ptr(self, name: str) -> int:
+        return self.flat.data_ptr() + 4 * self.offsets[name]
+
+    def g_ptr(self, name: str) -> int:
+        return self.grad.data_ptr() + 4 * self.offsets[name]
+
+    def grad_view(self, name: str, p: torch.nn.Parameter) -> torch.Tensor:
+        o = self.offsets[name]
+        return self.grad[o:o + p.numel()].view(p.shape)
+
+    def has(self, name: str) -> bool:
+        return name in self.offsets
+
+
+class Engine:
+    """Workspace + kernel sequencing for a fixed (B, T) shape."""
+
+    def __init__(self, model, B: int, T: int, device: torch.device, dtype: int):
+        cfg = model.cfg
+        self.model, self.cfg, self.B, self.T, self.device, self.dtype = model, cfg, B, T, device, dtype
+        self.tdtype = torch.bfloat16 if dtype == EG_BF16 else torch.float32
+        self.es = 2 if dtype == EG_BF16 else 4
+        self.bk = 64 if dtype == EG_BF16 else 32
+        d, H = cfg.d_model, cfg.num_heads
+        if d % H != 0 or d // H != 32:
+            raise L.EgError(f"HIP attention core needs d_model/num_heads == 32 (got {d}/{H})")
+        if cfg.conv_layers != 2:
+            raise L.EgError("HIP path implements the reference's 2-layer temporal conv front-end (conv_layers=2)")
+        if d % 64 != 0 or cfg.d_ff % 64 != 0:
+            raise L.EgError("d_model and d_ff must be multiples of 64")
+        k, s = cfg.conv_kernel_size, cfg.conv_stride
+        pad = k // 2
+        self.k, self.s, self.pad = k, s, pad
+        self.NB = 2 * B
+        self.C = cfg.in_channels
+        self.Cp = _align(self.C, 8)
+        self.T1 = (T + 2 * pad - k) // s + 1
+        self.T2 = (self.T1 + 2 * pad - k) // s + 1
+        self.J = (k + s - 1) // s
+        self.K0 = _align(k * self.Cp, self.bk)                    # conv-0 GEMM depth (zero-padded)
+        self.Tp = _align(max(T + 2 * pad, s * (self.T1 - 1) + self.K0 // self.Cp + 1), 8)
+        self.U = (self.T1 + 2 * pad + s - 1) // s                   # backward-data rows per phase
+        self.R0 = self.U * s                                        # padded conv-0 output rows per window
+        self.RY = self.T2 + 2 * (self.J - 1)                        # padded dY rows per window (backward-data)
+        self.n_ibs = cfg.num_ibs_tokens
+        self.n_spec = self.C if cfg.use_spectrogram else 0
+        self.off = 1 + self.n_ibs + self.n_spec
+        self.S = self.off + self.T2
+        if self.S > cfg.max_len:
+            raise L.EgError(f"sequence length {self.S} exceeds max_len {cfg.max_len} of the positional table")
+        if self.S > 160:
+            raise L.EgError(f"sequence length {self.S} exceeds the attention core's limit of 160")
+        self.M = self.NB * self.S
+        self.fp: FlatParams = model._flat
+        self.stream = 0
+        self._alloc()
+        self.packed_version = -1
+
+    # ------------------------------------------------------------------------------------------
+    def _t(self, *shape, dtype=None):
+        return torch.zeros(*shape, device=self.device, dtype=dtype or self.tdtype)
+
+    def _alloc(self):
+        cfg, d, F, L_ = self.cfg, self.cfg.d_model, self.cfg.d_ff, self.cfg.num_layers
+        NB, M, S, H, B = self.NB, self.M, self.S, self.cfg.num_heads, self.B
+        f32 = torch.float32
+        w = {}
+        # packed parameters (compute dtype)
+        w["conv0"] = self._t(d, self.K0)
+        w["conv1"] = self._t(d, self.k * d)
+        w["conv1T"] = self._t(self.s, d, self.J * d)
+        w["pos"] = self._t(cfg.max_len, d)
+        for l in list(range(L_)) + (["x"] if cfg.use_cross_attention else []):
+            w[f"qkv{l}"] = self._t(3 * d, d)
+            w[f"qkvT{l}"] = self._t(d, 3 * d)
+            w[f"o{l}"] = self._t(d, d)
+            w[f"oT{l}"] = self._t(d, d)
+            w[f"bqkv{l}"] = self._t(3 * d, dtype=f32)
+            if l != "x":
+                w[f"w1{l}"] = self._t(F, d)
+                w[f"w1T{l}"] = self._t(d, F)
+                w[f"w2{l}"] = self._t(d, F)
+                w[f"w2T{l}"] = self._t(F, d)
+        w["sf"] = self._t(d, 3 * d)
+        w["sfT"] = self._t(3 * d, d)
+        w["c0"] = self._t(d, 3 * d)
+        w["c0T"] = self._t(3 * d, d)
+        if cfg.use_ibs:
+            w["i0"] = self._t(d // 2, d)
+            w["i0T"] = self._t(d, _align(d // 2, self.bk))
+        self.w = w
+        a = {}
+        a["xt"] = self._t(NB, self.Tp, self.Cp)
+        a["h0pad"] = self._t(NB, self.R0, d)
+        a["h1"] = self._t(NB * self.T2, d)
+        a["x0"] = self._t(M, d)
+        for l in range(L_):
+            a[f"qkv{l}"] = self._t(M, 3 * d)
+            a[f"lse{l}"] = self._t(NB, H, S, dtype=f32)
+            a[f"ctx{l}"] = self._t(M, d)
+            a[f"r1_{l}"] = self._t(M, d)
+            a[f"st1_{l}"] = self._t(M, 2, dtype=f32)
+            a[f"y1_{l}"] = self._t(M, d)
+            a[f"hff{l}"] = self._t(M, F)
+            a[f"r2_{l}"] = self._t(M, d)
+            a[f"st2_{l}"] = self._t(M, 2, dtype=f32)
+            a[f"x{l + 1}"] = self._t(M, d)
+        a["stf"] = self._t(M, 2, dtype=f32)
+        a["zn"] = self._t(M, d)
+        if cfg.use_cross_attention:
+            a["qkvx"] = self._t(M, 3 * d)
+            a["lsex"] = self._t(NB, H, S, dtype=f32)
+            a["ctxx"] = self._t(M, d)
+            a["rx"] = self._t(M, d)
+            a["stx"] = self._t(M, 2, dtype=f32)
+            a["zc"] = self._t(M, d)
+        a["cls1"] = self._t(B, d, dtype=f32)
+        a["cls2"] = self._t(B, d, dtype=f32)
+        a["comb"] = self._t(B, 3 * d)
+        a["zf"] = self._t(B, 3 * d)
+        a["hcl"] = self._t(B, d)
+        a["logits"] = self._t(B, cfg.num_classes, dtype=f32)
+        a["sloss"] = self._t(B, dtype=f32)
+        a["loss"] = self._t(1, dtype=f32)
+        if cfg.use_ibs:
+            a["ibs_pool_f"] = self._t(B, d, dtype=f32)
+            a["ibs_pool"] = self._t(B, d)
+            a["hib"] = self._t(B, d // 2)
+            a["ibs_logits"] = self._t(B, cfg.num_classes, dtype=f32)
+            a["ibs_sloss"] = self._t(B, dtype=f32)
+            a["ibs_loss"] = self._t(1, dtype=f32)
+        self.a = a
+        # backward temporaries (allocated lazily on the first backward)
+        self.g: Dict[str, torch.Tensor] = {}
+        # step state: pinned host mirror -> device struct
+        self.state_host = torch.zeros(8, dtype=torch.int32).pin_memory() if self.device.type == "cuda" else torch.zeros(8, dtype=torch.int32)
+        self.state_dev = torch.zeros(8, dtype=torch.int32, device=self.device)
+        self.set_state(seed=0, lr=0.0, step=1, grad_scale=1.0)
+
+    def _alloc_bwd(self):
+        if self.g:
+            return
+        d, F, M, B, NB = self.cfg.d_model, self.cfg.d_ff, self.M, self.B, self.NB
+        g = {}
+        for n in ("dzA", "dzB", "dr", "drm", "dctx", "dy1"):
+            g[n] = self._t(M, d)
+        g["dqkv"] = self._t(M, 3 * d)
+        g["dh"] = self._t(M, F)
+        g["dzf"] = self._t(B, 3 * d)
+        g["dcomb"] = self._t(B, 3 * d)
+        g["dhcl"] = self._t(B, d)
+        g["dlogits"] = self._t(B, self.cfg.num_classes, dtype=torch.float32)
+        if self.cfg.use_ibs:
+            g["dhib"] = self._t(B, d // 2)
+            g["dibs_pool"] = self._t(B, d)
+            g["dibs_logits"] = self._t(B, self.cfg.num_classes, dtype=torch.float32)
+        g["dy1pad"] = self._t(NB, self.RY, d)
+        g["dh0pad"] = self._t(NB, self.R0, d)
+        g["possum"] = self._t(self.S, d, dtype=torch.float32)
+        g["one"] = torch.ones(1, device=self.device, dtype=torch.float32)
+        # TN split-K partials: sized for the largest product (conv-1 weights / FFN)
+        self.tn_cap = 24 * 1024 * 1024  # floats (96 MB)
+        g["partial"] = self._t(self.tn_cap, dtype=torch.float32)
+        g["lnpart"] = self._t(512 * 2 * max(d, 8), dtype=torch.float32)
+        g["cspart"] = self._t(256 * max(3 * d, F), dtype=torch.float32)
+        self.g = g
+
+    # ------------------------------------------------------------------------------------------
+    def set_state(self, seed: int, lr: float, step: int, grad_scale: float = 1.0, beta1=0.9, beta2=0.999):
+        st = StepState(seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, lr, 1.0 - beta1 ** step, 1.0 - beta2 ** step,
+                       grad_scale, 1.0, 0.0)
+        C.memmove(self.state_host.data_ptr(), C.addressof(st), C.sizeof(st))
+        self.state_dev.copy_(self.state_host, non_blocking=True)
+
+    def read_state(self) -> StepState:
+        host = self.state_dev.cpu()
+        st = StepState()
+        C.memmove(C.addressof(st), host.data_ptr(), C.sizeof(st))
+        return st
+
+    @property
+    def st_ptr(self) -> int:
+        return self.state_dev.data_ptr()
+
+    def _cur_stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+
+    # ------------------------------------------------------------------------------------------
+    # thin wrappers
+    # ------------------------------------------------------------------------------------------
+    def gemm(self, A, W, Cout, M, N, K, *, a=None, c=None, r=None, p=None, ldw=None, bias=0, residual=0, gate=0,
+             out_pre=0, act=0, drop1=(0.0, 0), drop2=(0.0, 0), gate_scale=1.0):
+        dsc = GemmDesc()
+        dsc.A, dsc.W, dsc.C = A, W, Cout
+        dsc.bias, dsc.residual, dsc.gate, dsc.out_pre = bias or None, residual or None, gate or None, out_pre or None
+        dsc.state = self.st_ptr
+        dsc.a = a or rowmap(K)
+        dsc.c = c or rowmap(N)
+        dsc.r = r or dsc.c
+        dsc.p = p or dsc.c
+        dsc.M, dsc.N, dsc.K, dsc.ldw = M, N, K, ldw or K
+        dsc.act, dsc.dtype = act, self.dtype
+        dsc.drop1_p, dsc.drop1_site = drop1
+        dsc.drop2_p, dsc.drop2_site = drop2
+        dsc.gate_scale = gate_scale
+        call("eg_gemm_nt", C.byref(dsc), self.stream)
+
+    def wgrad(self, dY, X, out_w, M, N, K, *, y=None, x=None, out_b=0, conv=None, split_out=None):
+        """dW = dY^T X (+ db = colsum dY).  split_out: list of (grad_ptr, row0, rows) for fused weights."""
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        splits = max(1, min((M + 255) // 256, (768 + tiles - 1) // tiles, self.tn_cap // (N * K)))
+        dsc = GemmTNDesc()
+        dsc.dY, dsc.X, dsc.partial = dY, X, ptr(self.g["partial"])
+        dsc.y = y or rowmap(N)
+        dsc.x = x or rowmap(K)
+        dsc.M, dsc.N, dsc.K, dsc.splits, dsc.dtype = M, N, K, splits, self.dtype
+        call("eg_gemm_tn", C.byref(dsc), self.stream)
+        pp = ptr(self.g["partial"])
+        if conv is not None:
+            cin, kk, cp = conv
+            call("eg_unpack_conv_wgrad", pp, out_w, splits, N, cin, kk, cp, K, self.stream)
+        elif split_out is not None:
+            for gp, row0, rows in split_out:
+                call("eg_reduce_partials", pp + 4 * row0 * K, gp, rows * K, splits, N * K, 0, self.stream)
+        else:
+            call("eg_reduce_partials", pp, out_w, N * K, splits, N * K, 0, self.stream)
+        if out_b:
+            nblk = min(256, (M + 63) // 64)
+            call("eg_colsum", dY, dsc.y, M, N, ptr(self.g["cspart"]), nblk, self.dtype, self.stream)
+            if isinstance(out_b, (list, tuple)):
+                for gp, col0, cols in out_b:
+                    call("eg_reduce_partials", ptr(self.g["cspart"]) + 4 * col0, gp, cols, nblk, N, 0, self.stream)
+            else:
+                call("eg_reduce_partials", ptr(self.g["cspart"]), out_b, N, nblk, N, 0, self.stream)
+
+    def ln_fwd(self, x, gname, y, stats):
+        call("eg_layernorm_fwd", ptr(x), self.fp.p_ptr(gname + ".weight"), self.fp.p_ptr(gname + ".bias"), ptr(y),
+             ptr(stats), self.M, self.cfg.d_model, self.dtype, self.stream)
+
+    def ln_bwd(self, dy, x, stats, gname, dx, dx_drop=None, d1=(0.0, 0), d2=(0.0, 0)):
+        d = self.cfg.d_model
+        nblk = 512
+        call("eg_layernorm_bwd", ptr(dy), ptr(x), ptr(stats), self.fp.p_ptr(gname + ".weight"), ptr(dx), ptr(dx_drop),
+             ptr(self.g["lnpart"]), nblk, self.M, d, self.dtype, d1[0], d1[1], d2[0], d2[1], self.st_ptr, self.stream)
+        lp = ptr(self.g["lnpart"])
+        call("eg_reduce_partials", lp, self.fp.g_ptr(gname + ".weight"), d, nblk, 2 * d, 0, self.stream)
+        call("eg_reduce_partials", lp + 4 * d, self.fp.g_ptr(gname + ".bias"), d, nblk, 2 * d, 0, self.stream)
+
+    # ------------------------------------------------------------------------------------------
+    # parameter staging
+    # ------------------------------------------------------------------------------------------
+    def pack_params(self):
+        cfg, d, F, fp, w, dt, st = self.cfg, self.cfg.d_model, self.cfg.d_ff, self.fp, self.w, self.dtype, self.stream
+        call("eg_pack_conv_weight", fp.p_ptr("temporal_conv.convs.0.weight"), ptr(w["conv0"]), d, self.C, self.k, self.Cp,
+             self.K0, dt, st)
+        call("eg_pack_conv_weight", fp.p_ptr("temporal_conv.convs.1.weight"), ptr(w["conv1"]), d, d, self.k, d, self.k * d,
+             dt, st)
+        call("eg_pack_convT_weight", fp.p_ptr("temporal_conv.convs.1.weight"), ptr(w["conv1T"]), d, d, self.k, self.s, dt, st)
+        call("eg_cast", fp.p_ptr("pos_embed.pos_embed.weight"), ptr(w["pos"]), cfg.max_len * d, dt, st)
+
+        def attn_pack(pre, l):
+            for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                call("eg_cast", fp.p_ptr(f"{pre}{n}.weight"), ptr(w[f"qkv{l}"]) + i * d * d * self.es, d * d, dt, st)
+                call("eg_transpose_cast", fp.p_ptr(f"{pre}{n}.weight"), ptr(w[f"qkvT{l}"]) + i * d * self.es, d, d, 3 * d, dt, st)
+                call("eg_cast", fp.p_ptr(f"{pre}{n}.bias"), ptr(w[f"bqkv{l}"]) + 4 * i * d, d, EG_F32, st)
+            call("eg_cast", fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"o{l}"]), d * d, dt, st)
+            call("eg_transpose_cast", fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"oT{l}"]), d, d, d, dt, st)
+
+        for l in range(cfg.num_layers):
+            pre = f"encoder.layers.{l}."
+            attn_pack(pre + "mha.", l)
+            call("eg_cast", fp.p_ptr(pre + "ffn.linear1.weight"), ptr(w[f"w1{l}"]), F * d, dt, st)
+            call("eg_transpose_cast", fp.p_ptr(pre + "ffn.linear1.weight"), ptr(w[f"w1T{l}"]), F, d, F, dt, st)
+            call("eg_cast", fp.p_ptr(pre + "ffn.linear2.weight"), ptr(w[f"w2{l}"]), d * F, dt, st)
+            call("eg_transpose_cast", fp.p_ptr(pre + "ffn.linear2.weight"), ptr(w[f"w2T{l}"]), d, F, d, dt, st)
+        if cfg.use_cross_attention:
+            attn_pack("cross_attn.cross_attn.", "x")
+        call("eg_cast", fp.p_ptr("symmetric_fusion.proj.weight"), ptr(w["sf"]), 3 * d * d, dt, st)
+        call("eg_transpose_cast", fp.p_ptr("symmetric_fusion.proj.weight"), ptr(w["sfT"]), d, 3 * d, d, dt, st)
+        call("eg_cast", fp.p_ptr("classifier.0.weight"), ptr(w["c0"]), 3 * d * d, dt, st)
+        call("eg_transpose_cast", fp.p_ptr("classifier.0.weight"), ptr(w["c0T"]), d, 3 * d, d, dt, st)
+        if cfg.use_ibs:
+            call("eg_cast", fp.p_ptr("ibs_classifier.0.weight"), ptr(w["i0"]), (d // 2) * d, dt, st)
+            call("eg_transpose_cast", fp.p_ptr("ibs_classifier.0.weight"), ptr(w["i0T"]), d // 2, d, w["i0T"].shape[1], dt, st)
+        self.model._pack_extra(self)
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def forward(self, eeg1: torch.Tensor, eeg2: torch.Tensor, labels: Optional[torch.Tensor], train: bool):
+        cfg, d, F, H = self.cfg, self.cfg.d_model, self.cfg.d_ff, self.cfg.num_heads
+        B, NB, M, S, a, w, fp, es = self.B, self.NB, self.M, self.S, self.a, self.w, self.fp, self.es
+        self.stream = self._cur_stream()
+        st = self.stream
+        p = cfg.dropout if train else 0.0
+        p01 = 0.1 if train else 0.0
+        self.train_flags = (p, p01, train)
+        self.pack_params()
+        for i, x in enumerate((eeg1, eeg2)):
+            if x.dtype != torch.float32 or not x.is_contiguous() or tuple(x.shape) != (B, self.C, self.T):
+                raise L.EgError(f"input windows must be contiguous f32 [{B},{self.C},{self.T}], got {tuple(x.shape)} {x.dtype}")
+            call("eg_window_pack", ptr(x), ptr(a["xt"]) + i * B * self.Tp * self.Cp * es, B, self.C, self.T, self.Cp,
+                 self.pad, self.Tp, self.dtype, st)
+        # K1: conv0 as a GEMM over overlapping channel-last rows (D:154,171)
+        self.gemm(ptr(a["xt"]), ptr(w["conv0"]), ptr(a["h0pad"]) + self.pad * d * es, NB * self.T1, d, self.K0,
+                  a=rowmap(self.s * self.Cp, self.Tp * self.Cp, self.T1), c=rowmap(d, self.R0 * d, self.T1),
+                  bias=fp.p_ptr("temporal_conv.convs.0.bias"), act=L.ACT_RELU, drop1=(p01, SITE_CONV0))
+        # K2: conv1, epilogue writes token rows [off:] of the sequence with the positional rows added (D:158,171,174; A:120-126)
+        self.gemm(ptr(a["h0pad"]), ptr(w["conv1"]), ptr(a["x0"]) + self.off * d * es, NB * self.T2, d, self.k * d,
+                  a=rowmap(self.s * d, self.R0 * d, self.T2), c=rowmap(d, S * d, self.T2),
+                  r=rowmap(d, 0, self.T2), p=rowmap(d), bias=fp.p_ptr("temporal_conv.convs.1.bias"), act=L.ACT_RELU,
+                  drop1=(p01, SITE_CONV1), residual=ptr(w["pos"]) + self.off * d * es, out_pre=ptr(a["h1"]))
+        # CLS rows (D:1157) + pos row 0
+        call("eg_rows_bcast_f32", fp.p_ptr("cls_token"), fp.p_ptr("pos_embed.pos_embed.weight"), ptr(a["x0"]), NB, S, d, 1,
+             0, 1, self.dtype, st)
+        self.model._extra_tokens_fwd(self, eeg1, eeg2, train)
+        # encoder (A:292-295, 326-328), both streams batched (Siamese weights)
+        for l in range(cfg.num_layers):
+            pre, sites = f"encoder.layers.{l}.", _layer_sites(l)
+            x = a[f"x{l}"]
+            self.gemm(ptr(x), ptr(w[f"qkv{l}"]), ptr(a[f"qkv{l}"]), M, 3 * d, d, bias=ptr(w[f"bqkv{l}"]))
+            call("eg_attention_fwd", ptr(a[f"qkv{l}"]), ptr(a[f"ctx{l}"]), ptr(a[f"lse{l}"]), NB, S, H, 0, self.dtype, p,
+                 sites["attn"], self.st_ptr, st)
+            self.gemm(ptr(a[f"ctx{l}"]), ptr(w[f"o{l}"]), ptr(a[f"r1_{l}"]), M, d, d, bias=fp.p_ptr(pre + "mha.out_proj.bias"),
+                      drop1=(p, sites["drop1"]), residual=ptr(x))
+            self.ln_fwd(a[f"r1_{l}"], pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"])
+            self.gemm(ptr(a[f"y1_{l}"]), ptr(w[f"w1{l}"]), ptr(a[f"hff{l}"]), M, F, d, bias=fp.p_ptr(pre + "ffn.linear1.bias"),
+                      act=L.ACT_RELU, drop1=(p, sites["ffn_a"]))
+            self.gemm(ptr(a[f"hff{l}"]), ptr(w[f"w2{l}"]), ptr(a[f"r2_{l}"]), M, d, F, bias=fp.p_ptr(pre + "ffn.linear2.bias"),
+                      drop1=(p, sites["ffn_b"]), drop2=(p, sites["drop2"]), residual=ptr(a[f"y1_{l}"]))
+            self.ln_fwd(a[f"r2_{l}"], pre + "ln2", a[f"x{l + 1}"], a[f"st2_{l}"])
+        Lr = cfg.num_layers
+        self.ln_fwd(a[f"x{Lr}"], "encoder.norm", a["zn"], a["stf"])
+        z = a["zn"]
+        if cfg.use_cross_attention:
+            # D:966-974: both directions in one launch each (kv_shift = B pairs window b with b+B)
+            xs = _layer_sites(Lr)
+            self.gemm(ptr(z), ptr(w["qkvx"]), ptr(a["qkvx"]), M, 3 * d, d, bias=ptr(w["bqkvx"]))
+            call("eg_attention_fwd", ptr(a["qkvx"]), ptr(a["ctxx"]), ptr(a["lsex"]), NB, S, H, B, self.dtype, p, xs["attn"],
+                 self.st_ptr, st)
+            self.gemm(ptr(a["ctxx"]), ptr(w["ox"]), ptr(a["rx"]), M, d, d, bias=fp.p_ptr("cross_attn.cross_attn.out_proj.bias"),
+                      drop1=(p, xs["drop1"]), residual=ptr(z))
+            call("eg_layernorm_fwd", ptr(a["rx"]), fp.p_ptr("cross_attn.norm.weight"), fp.p_ptr("cross_attn.norm.bias"),
+                 ptr(a["zc"]), ptr(a["stx"]), M, d, self.dtype, st)
+            z = a["zc"]
+        self.z_final = z
+        # heads (D:1193-1213)
+        call("eg_pool_fuse_fwd", ptr(z), ptr(a["cls1"]), ptr(a["cls2"]), ptr(a["comb"]), ptr(a["zf"]),
+             ptr(a.get("ibs_pool_f")), ptr(a.get("ibs_pool")), B, S, d, self.off, self.n_ibs, 1, self.dtype, st)
+        self.gemm(ptr(a["comb"]), ptr(w["sf"]), ptr(a["zf"]), B, d, 3 * d, c=rowmap(3 * d),
+                  bias=fp.p_ptr("symmetric_fusion.proj.bias"))
+        self.gemm(ptr(a["zf"]), ptr(w["c0"]), ptr(a["hcl"]), B, d, 3 * d, bias=fp.p_ptr("classifier.0.bias"),
+                  act=L.ACT_RELU, drop1=(p, SITE_CLS))
+        lab = ptr(labels) if labels is not None else 0
+        call("eg_classifier_ce_fwd", ptr(a["hcl"]), fp.p_ptr("classifier.3.weight"), fp.p_ptr("classifier.3.bias"), lab,
+             ptr(a["logits"]), ptr(a["sloss"]), ptr(a["loss"]), B, d, cfg.num_classes, self.dtype, st)
+        if cfg.use_ibs:
+            p3 = 0.3 if train else 0.0
+            self.gemm(ptr(a["ibs_pool"]), ptr(w["i0"]), ptr(a["hib"]), B, d // 2, d, bias=fp.p_ptr("ibs_classifier.0.bias"),
+                      act=L.ACT_RELU, drop1=(p3, SITE_IBSCLS))
+            call("eg_classifier_ce_fwd", ptr(a["hib"]), fp.p_ptr("ibs_classifier.3.weight"), fp.p_ptr("ibs_classifier.3.bias"),
+                 lab, ptr(a["ibs_logits"]), ptr(a["ibs_sloss"]), ptr(a["ibs_loss"]), B, d // 2, cfg.num_classes, self.dtype, st)
+        self.labels = labels
+
+    # ------------------------------------------------------------------------------------------
+    # backward.  g* arguments are optional fp32 device tensors (gradients of the module's outputs);
+    # gloss / gloss_ibs are 1-element fp32 device tensors (d total / d loss_ce, d total / d loss_ibs_cls).
+    # Gradients land in the flat gradient buffer (overwritten, not accumulated).
+    # ------------------------------------------------------------------------------------------
+    def backward(self, gloss=None, gloss_ibs=None, glogits=None, gcls1=None, gcls2=None, gibs_logits=None,
+                 gibs_token=None, on_segment=None):
+        self._alloc_bwd()
+        cfg, d, F, H = self.cfg, self.cfg.d_model, self.cfg.d_ff, self.cfg.num_heads
+        B, NB, M, S, a, w, fp, g, es = self.B, self.NB, self.M, self.S, self.a, self.w, self.fp, self.g, self.es
+        self.stream = self._cur_stream()
+        st = self.stream
+        p, p01, train = self.train_flags
+        sc = 1.0 / (1.0 - p) if p > 0 else 1.0
+        sc01 = 1.0 / (1.0 - p01) if p01 > 0 else 1.0
+        lab = ptr(self.labels) if self.labels is not None else 0
+        seg = on_segment or (lambda name: None)
+        # ---- heads ----
+        call("eg_classifier_ce_bwd", ptr(a["hcl"]), fp.p_ptr("classifier.3.weight"), ptr(a["logits"]), lab, ptr(gloss),
+             ptr(glogits), ptr(g["dlogits"]), ptr(g["dhcl"]), fp.g_ptr("classifier.3.weight"), fp.g_ptr("classifier.3.bias"),
+             B, d, cfg.num_classes, 1, sc, self.dtype, st)
+        self.gemm(ptr(g["dhcl"]), ptr(w["c0T"]), ptr(g["dzf"]), B, 3 * d, d)
+        self.wgrad(ptr(g["dhcl"]), ptr(a["zf"]), fp.g_ptr("classifier.0.weight"), B, d, 3 * d, out_b=fp.g_ptr("classifier.0.bias"))
+        self.gemm(ptr(g["dzf"]), ptr(w["sfT"]), ptr(g["dcomb"]), B, 3 * d, d, a=rowmap(3 * d))
+        self.wgrad(ptr(g["dzf"]), ptr(a["comb"]), fp.g_ptr("symmetric_fusion.proj.weight"), B, d, 3 * d, y=rowmap(3 * d),
+                   out_b=fp.g_ptr("symmetric_fusion.proj.bias"))
+        dibs = None
+        if cfg.use_ibs:
+            sc3 = 1.0 / 0.7 if train else 1.0
+            call("eg_classifier_ce_bwd", ptr(a["hib"]), fp.p_ptr("ibs_classifier.3.weight"), ptr(a["ibs_logits"]), lab,
+                 ptr(gloss_ibs), ptr(gibs_logits), ptr(g["dibs_logits"]), ptr(g["dhib"]), fp.g_ptr("ibs_classifier.3.weight"),
+                 fp.g_ptr("ibs_classifier.3.bias"), B, d // 2, cfg.num_classes, 1, sc3, self.dtype, st)
+            Kp = w["i0T"].shape[1]
+            if Kp != d // 2:
+                raise L.EgError("ibs_classifier hidden width must be a multiple of the GEMM K-tile")
+            self.gemm(ptr(g["dhib"]), ptr(w["i0T"]), ptr(g["dibs_pool"]), B, d, d // 2)
+            self.wgrad(ptr(g["dhib"]), ptr(a["ibs_pool"]), fp.g_ptr("ibs_classifier.0.weight"), B, d // 2, d,
+                       out_b=fp.g_ptr("ibs_classifier.0.bias"))
+            dibs = g["dibs_pool"]
+        z = self.z_final
+        dz = g["dzA"]
+        call("eg_pool_fuse_bwd", ptr(z), ptr(g["dcomb"]), ptr(g["dzf"]), ptr(gcls1), ptr(gcls2), ptr(dibs), ptr(gibs_token),
+             ptr(dz), B, S, d, self.off, self.n_ibs, 1, self.dtype, st)
+        seg("heads")
+        Lr = cfg.num_layers
+        other = g["dzB"]
+
+        def attn_block_bwd(pre, l, x_in, dr, drm, kv_shift, site_attn, dx_out):
+            """dr: grad of the pre-LN sum (residual path), drm: same, masked by the branch dropout."""
+            names = [pre + n for n in ("q_proj", "k_proj", "v_proj")]
+            self.wgrad(ptr(drm), ptr(a[f"ctx{l}"]), fp.g_ptr(pre + "out_proj.weight"), M, d, d,
+                       out_b=fp.g_ptr(pre + "out_proj.bias"))
+            self.gemm(ptr(drm), ptr(w[f"oT{l}"]), ptr(g["dctx"]), M, d, d)
+            call("eg_attention_bwd", ptr(a[f"qkv{l}"]), ptr(a[f"ctx{l}"]), ptr(g["dctx"]), ptr(a[f"lse{l}"]), ptr(g["dqkv"]),
+                 NB, S, H, kv_shift, self.dtype, p, site_attn, self.st_ptr, st)
+            self.wgrad(ptr(g["dqkv"]), ptr(x_in), 0, M, 3 * d, d,
+                       split_out=[(fp.g_ptr(n + ".weight"), i * d, d) for i, n in enumerate(names)],
+                       out_b=[(fp.g_ptr(n + ".bias"), i * d, d) for i, n in enumerate(names)])
+            self.gemm(ptr(g["dqkv"]), ptr(w[f"qkvT{l}"]), ptr(dx_out), M, d, 3 * d, residual=ptr(dr))
+
+        if cfg.use_cross_attention:
+            xs = _layer_sites(Lr)
+            has_drop = p > 0
+            self.ln_bwd(dz, a["rx"], a["stx"], "cross_attn.norm", g["dr"], g["drm"] if has_drop else None, d1=(p, xs["drop1"]))
+            drm = g["drm"] if has_drop else g["dr"]
+            attn_block_bwd("cross_attn.cross_attn.", "x", a["zn"], g["dr"], drm, B, xs["attn"], other)
+            dz, other = other, dz
+            seg("cross")
+        # final encoder norm (A:328)
+        self.ln_bwd(dz, a[f"x{Lr}"], a["stf"], "encoder.norm", other)
+        dz, other = other, dz
+        seg("encoder.norm")
+        for l in reversed(range(Lr)):
+            pre, sites = f"encoder.layers.{l}.", _layer_sites(l)
+            has_drop = p > 0
+            self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", g["dr"], g["drm"] if has_drop else None,
+                        d1=(p, sites["ffn_b"]), d2=(p, sites["drop2"]))
+            drm = g["drm"] if has_drop else g["dr"]
+            self.wgrad(ptr(drm), ptr(a[f"hff{l}"]), fp.g_ptr(pre + "ffn.linear2.weight"), M, d, F,
+                       out_b=fp.g_ptr(pre + "ffn.linear2.bias"))
+            self.gemm(ptr(drm), ptr(w[f"w2T{l}"]), ptr(g["dh"]), M, F, d, gate=ptr(a[f"hff{l}"]), gate_scale=sc)
+            self.wgrad(ptr(g["dh"]), ptr(a[f"y1_{l}"]), fp.g_ptr(pre + "ffn.linear1.weight"), M, F, d,
+                       out_b=fp.g_ptr(pre + "ffn.linear1.bias"))
+            self.gemm(ptr(g["dh"]), ptr(w[f"w1T{l}"]), ptr(g["dy1"]), M, d, F, residual=ptr(g["dr"]))
+            self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", g["dr"], g["drm"] if has_drop else None,
+                        d1=(p, sites["drop1"]))
+            drm = g["drm"] if has_drop else g["dr"]
+            attn_block_bwd(pre + "mha.", l, a[f"x{l}"], g["dr"], drm, 0, sites["attn"], other)
+            dz, other = other, dz
+            seg(f"layer{l}")
+        dseq = dz
+        # positional table / cls token (A:120-126, D:1157)
+        call("eg_batch_rowsum", ptr(dseq), fp.g_ptr("pos_embed.pos_embed.weight"), NB, S, d, S, self.dtype, st)
+        call("eg_cast", fp.g_ptr("pos_embed.pos_embed.weight"), fp.g_ptr("cls_token"), d, EG_F32, st)
+        self.model._extra_tokens_bwd(self, dseq)
+        # conv1 backward: dY = dseq[:, off:, :] * relu/dropout gate
+        ymap = rowmap(d, self.RY * d, self.T2)
+        call("eg_rows_gather_gate", ptr(dseq), ptr(a["h1"]), ptr(g["dy1pad"]) + (self.J - 1) * d * es, ymap, NB, S, d,
+             self.T2, self.off, 0, sc01, self.dtype, st)
+        dy1 = ptr(g["dy1pad"]) + (self.J - 1) * d * es
+        self.wgrad(dy1, ptr(a["h0pad"]), fp.g_ptr("temporal_conv.convs.1.weight"), NB * self.T2, d, self.k * d, y=ymap,
+                   x=rowmap(self.s * d, self.R0 * d, self.T2), out_b=fp.g_ptr("temporal_conv.convs.1.bias"),
+                   conv=(d, self.k, d))
+        for ph in range(self.s):
+            self.gemm(ptr(g["dy1pad"]), ptr(w["conv1T"]) + ph * d * self.J * d * es, ptr(g["dh0pad"]) + ph * d * es,
+                      NB * self.U, d, self.J * d, a=rowmap(d, self.RY * d, self.U), c=rowmap(self.s * d, self.R0 * d, self.U),
+                      gate=ptr(a["h0pad"]) + ph * d * es, gate_scale=sc01)
+        h0map = rowmap(d, self.R0 * d, self.T1)
+        self.wgrad(ptr(g["dh0pad"]) + self.pad * d * es, ptr(a["xt"]), fp.g_ptr("temporal_conv.convs.0.weight"),
+                   NB * self.T1, d, self.K0, y=h0map, x=rowmap(self.s * self.Cp, self.Tp * self.Cp, self.T1),
+                   out_b=fp.g_ptr("temporal_conv.convs.0.bias"), conv=(self.C, self.k, self.Cp))
+        seg("frontend")
+
+    # ------------------------------------------------------------------------------------------
+    # optimiser: clip_grad_norm_(max_norm) + AdamW on the flat buffers (T:221-222)
+    # ------------------------------------------------------------------------------------------
+    def optimizer_step(self, m: torch.Tensor, v: torch.Tensor, max_norm: float = 1.0, betas=(0.9, 0.999), eps=1e-8,
+                       weight_decay=0.01):
+        self._alloc_bwd()
+        self.stream = self._cur_stream()
+        nblk = 1024
+        if "sqpart" not in self.g:
+            self.g["sqpart"] = self._t(nblk, dtype=torch.float32)
+        call("eg_grad_sqnorm", ptr(self.fp.grad), self.fp.total, ptr(self.g["sqpart"]), nblk, self.stream)
+        call("eg_clip_coef", ptr(self.g["sqpart"]), nblk, max_norm, self.st_ptr, self.stream)
+        call("eg_adamw", ptr(self.fp.flat), ptr(self.fp.grad), ptr(m), ptr(v), self.fp.total, betas[0], betas[1], eps,
+             weight_decay, self.st_ptr, self.stream)

@@ -1,0 +1,205 @@
+/*
+ * eyegaze_hip.h — C ABI of libeyegaze_hip.so: the MI355X (gfx950) kernels behind the reference's
+ * dual-stream window classifier hot path
+ *     run_experiments.py -> 4_Experiments/scripts/train_art.py::train_epoch/evaluate
+ *       -> 3_Models/backbones/dual_eeg_transformer.py::DualEEGTransformer.forward (+ art.py encoder)
+ *       -> loss -> backward -> clip -> AdamW.
+ *
+ * The reference has no FFI of its own (it is pure PyTorch); its seam is the nn.Module interface
+ * (dual_eeg_transformer.py:995-1021 ctor, :1110-1253 forward).  A maintainer binds this library with
+ * ctypes from a drop-in `DualEEGTransformer` (see INTEGRATION.md and
+ * eyegaze_multimodal_amd/dual_eeg_transformer.py).  Each entry point below names the reference lines
+ * whose arithmetic it replaces ("D:" = dual_eeg_transformer.py, "A:" = art.py, "T:" = train_art.py).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed or owned by a torch tensor) unless marked host;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); all work is stream-ordered,
+ *     nothing synchronises, nothing allocates;
+ *   - dtype: EG_F32 (exact fp32 path, v_mfma_f32_16x16x4_f32) or EG_BF16 (bf16 storage, fp32 accumulate,
+ *     v_mfma_f32_16x16x32_bf16).  Parameters, gradients, optimiser state, LayerNorm statistics,
+ *     soft-max statistics and losses are always fp32;
+ *   - return value: 0 on success, non-zero on a rejected call (eg_last_error() gives the text).
+ *     Shape/argument checks happen on the host BEFORE any launch.
+ */
+#ifndef EYEGAZE_HIP_H
+#define EYEGAZE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EG_ABI_VERSION 1
+enum { EG_F32 = 0, EG_BF16 = 1 };
+enum { EG_ACT_NONE = 0, EG_ACT_RELU = 1, EG_ACT_GELU = 2 };
+
+int eg_abi_version(void);
+const char* eg_last_error(void);
+/* fills cu_count / arch name of the current device (host pointers) */
+int eg_device_info(int* cu_count, char* arch, int arch_len);
+
+/* Device-resident per-step scalars.  Kernels read them from memory (not from kernel arguments) so a
+ * captured hipGraph of one training step replays correctly with a new seed / learning rate. */
+typedef struct eg_step_state {
+  uint32_t seed_lo, seed_hi; /* dropout seed of this step */
+  float lr;                  /* learning rate (cosine schedule, T:409/494) */
+  float bias_corr1;          /* 1 - beta1^t */
+  float bias_corr2;          /* 1 - beta2^t */
+  float grad_scale;          /* multiplies gradients before clipping (1/world_size for a summed all-reduce) */
+  float clip_coef;           /* written by eg_clip_coef: min(1, max_norm/(norm+1e-6)) (T:221) */
+  float grad_norm;           /* written by eg_clip_coef: global L2 norm before clipping */
+} eg_step_state;
+
+/* Grouped row addressing: row r of a logical [M, *] matrix starts at element
+ *   (r / rows_per_group) * group_stride + (r % rows_per_group) * row_stride
+ * rows_per_group == 0 means plain rows (r * row_stride).  This is how the strided 1-D convolutions read
+ * overlapping windows of a channel-last, zero-padded signal as GEMM rows without an im2col copy. */
+typedef struct eg_rowmap {
+  int64_t row_stride;
+  int64_t group_stride;
+  int32_t rows_per_group;
+  int32_t _pad;
+} eg_rowmap;
+
+/* ---------------------------------------------------------------------------------------------
+ * Input staging — D:1127-1128 feed, 1_Data/processed/dual_eeg_dataset.py:236-248 layout [B,C,T] f32
+ * x [NB, C, T] f32  ->  xt [NB, Tp, Cp] (dtype), channel-last, `pad_front` zero time steps in front,
+ * zeros behind up to Tp, channels C..Cp-1 zero.  Coalesced reads along T, LDS transpose.
+ * ------------------------------------------------------------------------------------------- */
+int eg_window_pack(const float* x, void* xt, int NB, int C, int T, int Cp, int pad_front, int Tp, int dtype,
+                   void* stream);
+
+/* Parameter staging (fp32 master -> compute dtype copies), run once per optimiser step.
+ *   eg_cast:             n contiguous elements
+ *   eg_transpose_cast:   src [R, Cc] f32 -> dst[c*ldd + r]         (weights for backward-data GEMMs)
+ *   eg_pack_conv_weight: w [N, Cin, k] f32 -> dst [N, Kp], dst[n][tap*Cp + c] = w[n][c][tap], zero padded
+ *                        (D:154,158 Conv1d weights in the tap-major order the channel-last GEMM rows need)
+ *   eg_pack_convT_weight: backward-data weights of the stride-s conv, one matrix per output phase p:
+ *                        dst[p][c][j*N + n] = w[n][c][s*(J-1-j) + p] (0 where the tap is > k-1), J = ceil(k/s)
+ */
+int eg_cast(const float* src, void* dst, int64_t n, int dtype, void* stream);
+int eg_transpose_cast(const float* src, void* dst, int R, int Cc, int ldd, int dtype, void* stream);
+int eg_pack_conv_weight(const float* w, void* dst, int N, int Cin, int k, int Cp, int Kp, int dtype, void* stream);
+int eg_pack_convT_weight(const float* w, void* dst, int N, int Cin, int k, int stride, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * eg_gemm_nt — the MFMA workhorse.  Y = epilogue(A[M,K] * W[N,K]^T)
+ *   replaces: Conv1d+ReLU+Dropout (D:154-171) via grouped rows, q/k/v/out projections (A:203-213),
+ *   FeedForward linears (A:272), head linears (D:939, D:1100-1105, D:1074-1079), tokenizer / spectrogram
+ *   projections (D:81-86, D:863-868) and every backward-data product.
+ *   epilogue, in this order:  v = acc + bias[n]; v = act(v); v = gate>0 ? v*gate_scale : 0; v = drop1(v);
+ *   v = drop2(v); if (out_pre) out_pre = v; v += residual; C = v
+ *   K % (128/sizeof(elem)) == 0, N % 8 == 0; rows beyond M are neither read past nor written.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct eg_gemm_desc {
+  const void* A;        /* activations, rows addressed by `a` */
+  const void* W;        /* [N, ldw] row-major, K contiguous */
+  void* C;              /* rows addressed by `c` */
+  const float* bias;    /* [N] fp32 or NULL */
+  const void* residual; /* rows addressed by `r`, same dtype, or NULL */
+  const void* gate;     /* rows addressed by `c`; output zeroed where gate <= 0 (ReLU backward), or NULL */
+  void* out_pre;        /* rows addressed by `p`; value before the residual add, or NULL */
+  const eg_step_state* state; /* dropout seed; may be NULL when both p are 0 */
+  eg_rowmap a, c, r, p; /* p addresses out_pre */
+  int32_t M, N, K, ldw;
+  int32_t act;
+  int32_t dtype;
+  float drop1_p, drop2_p;
+  uint32_t drop1_site, drop2_site;
+  float gate_scale; /* 1/(1-p) of the dropout that followed the gated ReLU in the forward pass, else 1 */
+} eg_gemm_desc;
+int eg_gemm_nt(const eg_gemm_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * eg_gemm_tn — weight-gradient product  dW[N,K] = sum_m dY[m,n] * X[m,k]  (fp32 result)
+ *   replaces autograd's grad_weight of every Linear / Conv1d above.  Reads both operands row-major
+ *   (rows = the reduction index) and transposes on the LDS read (ds_read_b64_tr_b16).  The reduction over
+ *   M is split over `splits` workgroups; partials [splits, N, K] fp32 go to `partial` and
+ *   eg_reduce_partials sums them (deterministic, no atomics).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct eg_gemm_tn_desc {
+  const void* dY; /* [M, N] rows addressed by `y` */
+  const void* X;  /* [M, K] rows addressed by `x` */
+  float* partial; /* [splits, N, K] fp32 workspace */
+  eg_rowmap y, x;
+  int32_t M, N, K, splits;
+  int32_t dtype;
+} eg_gemm_tn_desc;
+int eg_gemm_tn(const eg_gemm_tn_desc* d, void* stream);
+/* out[i] = (accumulate ? out[i] : 0) + sum_s partial[s*split_stride + i]; used for dW, db, LayerNorm dgamma/dbeta */
+int eg_reduce_partials(const float* partial, float* out, int64_t n, int splits, int64_t split_stride, int accumulate,
+                       void* stream);
+/* conv weight gradient back to the parameter layout: dW[n][c][tap] = sum_s partial[s][n][tap*Cp + c] */
+int eg_unpack_conv_wgrad(const float* partial, float* dW, int splits, int N, int Cin, int k, int Cp, int Kp,
+                         void* stream);
+/* column sums: out_partial[blk, n] = sum over the block's rows of Y[m, n]; rows addressed by `y` */
+int eg_colsum(const void* Y, eg_rowmap y, int M, int N, float* partial, int nblk, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm(eps=1e-5) over the last dim  — A:283,286,293,295,306,328; D:952,968,972
+ *   fwd: y = (x-mean)*rstd*gamma+beta, stats [M,2] = (mean, rstd)
+ *   bwd: dx from dy; per-block partial dgamma/dbeta [nblk, 2, D] (sum with eg_reduce_partials);
+ *        optional dx_drop = dropout-masked dx (the gradient entering the branch whose output was dropped
+ *        before the residual add: drop1/drop2 of A:293,295 and the FeedForward's own final dropout A:272)
+ * ------------------------------------------------------------------------------------------- */
+int eg_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int D,
+                     int dtype, void* stream);
+int eg_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, void* dx_drop,
+                     float* partial, int nblk, int M, int D, int dtype, float drop1_p, uint32_t drop1_site,
+                     float drop2_p, uint32_t drop2_site, const eg_step_state* state, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-head attention core on a fused [NB*S, 3*D] q|k|v buffer — A:206-212; cross form D:967,971
+ *   head h of sample b attends over the keys/values of sample (b + kv_shift) mod NB
+ *   (kv_shift = 0: Siamese self-attention; kv_shift = NB/2: CrossBrainAttention, both directions at once).
+ *   d_k must be 32.  lse [NB, H, S] = log-sum-exp of the scaled scores (for the backward recompute).
+ *   attention-probability dropout (A:210) uses site `drop_site`.
+ * ------------------------------------------------------------------------------------------- */
+int eg_attention_fwd(const void* qkv, void* ctx, float* lse, int NB, int S, int H, int kv_shift, int dtype,
+                     float drop_p, uint32_t drop_site, const eg_step_state* state, void* stream);
+int eg_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int NB, int S,
+                     int H, int kv_shift, int dtype, float drop_p, uint32_t drop_site, const eg_step_state* state,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sequence assembly and heads (all [B, d]-sized, latency-bound single launches)
+ *   eg_rows_bcast_f32  seq[b, off+r, :] = src[b % src_nb, r, :] + pos[off+r, :]   (cls_token expand + pos, D:1157,1178)
+ *   eg_rows_copy       seq[b_dst0+b, off+r, :] = seq[b_src0+b, off+r, :]          (shared IBS tokens, D:1163-1165)
+ *   eg_pool_fuse_fwd   cls slices, mean pools, symmetric-fusion operands          (D:1193-1212, D:933-938, D:1222-1223)
+ *   eg_classifier_ce_* last Linear(K -> ncls<=16) fused with cross-entropy         (D:1104, D:1078, D:1244, D:1250)
+ *   eg_batch_rowsum    out[s,:] = sum_b dseq[b,s,:]  (pos_embed / cls_token gradients)
+ *   eg_rows_gather_gate dst rows = (src[b, off+r] (+ src[b+pair_shift, off+r])) * relu-gate * gate_scale
+ * ------------------------------------------------------------------------------------------- */
+int eg_rows_bcast_f32(const float* src, const float* pos, void* seq, int NB, int S, int D, int R, int off, int src_nb,
+                      int dtype, void* stream);
+int eg_rows_copy(void* seq, int S, int D, int R, int off, int b_src0, int b_dst0, int nb, int dtype, void* stream);
+int eg_pool_fuse_fwd(const void* z, float* cls1, float* cls2, void* comb, void* zf, float* ibs_pool_f, void* ibs_pool,
+                     int B, int S, int D, int off, int n_ibs, int ibs_first, int dtype, void* stream);
+int eg_pool_fuse_bwd(const void* z, const void* dcomb, const void* dzf, const float* gcls1, const float* gcls2,
+                     const void* dibs_pool, const float* gibs_pool, void* dz, int B, int S, int D, int off, int n_ibs,
+                     int ibs_first, int dtype, void* stream);
+int eg_classifier_ce_fwd(const void* h, const float* W, const float* bias, const int64_t* labels, float* logits,
+                         float* sample_loss, float* loss, int B, int K, int ncls, int dtype, void* stream);
+int eg_classifier_ce_bwd(const void* h, const float* W, const float* logits, const int64_t* labels, const float* gloss,
+                         const float* glogits, float* dlogits, void* dh, float* dW, float* db, int B, int K, int ncls,
+                         int use_gate, float gate_scale, int dtype, void* stream);
+int eg_batch_rowsum(const void* dseq, float* out, int NB, int S, int D, int rows, int dtype, void* stream);
+int eg_rows_gather_gate(const void* src, const void* gate, void* dst, eg_rowmap dmap, int nb, int S, int D, int R,
+                        int off, int pair_shift, float gate_scale, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser over flat fp32 buffers — clip_grad_norm_(1.0) + AdamW (T:221-222, T:401-405)
+ *   eg_grad_sqnorm: partial[blk] = sum of squares;  eg_clip_coef: state->grad_norm / clip_coef (no host sync)
+ *   eg_adamw: p *= 1-lr*wd; m,v update with g*grad_scale*clip_coef; p -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps)
+ * ------------------------------------------------------------------------------------------- */
+int eg_grad_sqnorm(const float* g, int64_t n, float* partial, int nblk, void* stream);
+int eg_clip_coef(const float* partial, int nblk, float max_norm, eg_step_state* state, void* stream);
+int eg_adamw(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+             float weight_decay, const eg_step_state* state, void* stream);
+int eg_fill_f32(float* p, int64_t n, float value, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EYEGAZE_HIP_H */

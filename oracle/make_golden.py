@@ -189,6 +189,11 @@ def run_config(name, kw, model_mod, gen_mod, out_dir: Path):
     blob["aux/align"] = model.compute_ibs_alignment_loss(ibs, c1, c2).detach().numpy()
     blob["aux/contrastive"] = model.compute_ibs_contrastive_loss(ibs, lab).detach().numpy()
     blob["aux/contrastive_nopos"] = model.compute_ibs_contrastive_loss(ibs[:3], torch.tensor([0, 1, 2])).detach().numpy()
+    # default initialisation under torch.manual_seed(42): per-tensor checksums pin the RNG consumption order
+    torch.manual_seed(42)
+    fresh = model_mod.DualEEGTransformer(**kw)
+    blob["init42/sum"] = np.array([float(v.double().sum()) for v in fresh.state_dict().values()])
+    blob["init42/abs"] = np.array([float(v.double().abs().sum()) for v in fresh.state_dict().values()])
     blob["cfg_json"] = np.array(repr(kw))
     path = out_dir / f"{name}.npz"
     np.savez_compressed(path, **{k: (v if isinstance(v, np.ndarray) else np.asarray(v)) for k, v in blob.items()})

@@ -1,0 +1,56 @@
+"""CPU-only: the C-ABI library builds, loads, and exports every symbol include/eyegaze_hip.h declares
+(no compute calls without a GPU), and the ctypes binding lists the same set."""
+import re
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    text = (REPO / "include" / "eyegaze_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(eg_\w+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from eyegaze_multimodal_amd import build
+    lib_path = build.build(verbose=False)
+    assert lib_path.exists()
+    import ctypes
+    lib = ctypes.CDLL(str(lib_path))
+    names = declared_symbols()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.eg_abi_version.restype = ctypes.c_int
+    assert lib.eg_abi_version() == 1
+
+
+def test_binding_covers_the_header():
+    from eyegaze_multimodal_amd import _lib
+    names = set(declared_symbols())
+    bound = set(_lib.SIGNATURES) | {"eg_abi_version", "eg_last_error"}
+    assert names <= bound, sorted(names - bound)
+    exported = _lib.exported_symbols()
+    assert all(exported[n] for n in names), [n for n in names if not exported[n]]
+
+
+def test_host_side_argument_checks_run_without_a_gpu():
+    """Shape/argument validation happens before any launch, so a rejected call is observable on CPU."""
+    import ctypes as C
+    from eyegaze_multimodal_amd import _lib as L
+    d = L.GemmDesc()
+    with pytest.raises(L.EgError, match="null operand"):
+        L.call("eg_gemm_nt", C.byref(d), 0)
+    with pytest.raises(L.EgError, match="bad arguments"):
+        L.call("eg_adamw", 0, 0, 0, 0, 10, 0.9, 0.999, 1e-8, 0.01, 0, 0)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from eyegaze_multimodal_amd import _lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(L.EgError, match="no CPU fallback"):
+        L.lib()

@@ -1,0 +1,188 @@
+"""GPU parity tests, model level: the HIP DualEEGTransformer against the golden fixtures emitted by the
+reference (tests/golden, see oracle/make_golden.py) and against the CPU oracle on fresh seeded inputs.
+
+Tolerances (SURVEY.md §8c evidence: reference fp32 vs fp64 differs by ~2e-7 on logits):
+  bf16 compute (bf16 storage, fp32 accumulate):  |dlogit| <= 3e-2, argmax equal wherever the reference's
+      top-2 margin exceeds 6e-2 (all fixture samples do); stage tensors rtol 3e-2 of their max-abs.
+  f32 compute (exact-fp32 MFMA, where a kernel exists): |dlogit| <= 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from eyegaze_multimodal_amd import DualEEGTransformer, HipAdamW  # noqa: E402
+from eyegaze_multimodal_amd import _lib as L  # noqa: E402
+from oracle import dual_eeg_oracle as O  # noqa: E402
+from tests.helpers import load_golden, t  # noqa: E402
+
+DEV = "cuda"
+BASE_CONFIGS = ["cfg1_a1_2class", "cfg2_concat", "cfg3_xattn", "tiny_a1"]
+
+
+def build(name, dtype="bf16"):
+    z, kw, cfg, sd = load_golden(name)
+    model = DualEEGTransformer(**kw, compute_dtype=dtype)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    model.load_state_dict(sd, strict=True)
+    return z, kw, cfg, sd, model.to(DEV)
+
+
+def relerr(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("name", BASE_CONFIGS)
+@pytest.mark.parametrize("kind", ["randn", "gen_eeg"])
+def test_eval_forward_matches_reference(name, kind):
+    z, kw, cfg, sd, model = build(name)
+    model.eval()
+    x1, x2, labels = t(z[f"{kind}/eeg1"]).to(DEV), t(z[f"{kind}/eeg2"]).to(DEV), t(z["labels"]).to(DEV)
+    with torch.no_grad():
+        out = model(x1, x2, labels)
+    torch.cuda.synchronize()
+    ref_logits = z[f"{kind}/out/logits"]
+    got = out["logits"].cpu().numpy()
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref_logits).max()
+    assert err <= 3e-2, f"logits err {err}"
+    top2 = np.sort(ref_logits, -1)
+    decided = (top2[:, -1] - top2[:, -2]) > 6e-2
+    assert (got.argmax(-1)[decided] == z[f"{kind}/out/argmax"][decided]).all()
+    assert abs(float(out["loss_ce"]) - float(z[f"{kind}/out/loss_ce"])) < 2e-2
+    for k in ("cls1", "cls2"):
+        assert relerr(out[k].cpu(), z[f"{kind}/out/{k}"]) < 3e-2, k
+    eng = next(iter(model._engines.values()))
+    NB, S, d = eng.NB, eng.S, cfg.d_model
+    h1 = eng.a["h1"].float().cpu().view(NB, eng.T2, d)[:2]
+    assert relerr(h1, z[f"{kind}/stage/h1"]) < 2e-2
+    zn = eng.a["zn"].float().cpu().view(NB, S, d)[:2]
+    assert relerr(zn, z[f"{kind}/stage/z1"]) < 3e-2
+    if cfg.use_cross_attention:
+        zc = eng.a["zc"].float().cpu().view(NB, S, d)[:2]
+        assert relerr(zc, z[f"{kind}/stage/zc1"]) < 3e-2
+
+
+@pytest.mark.parametrize("name", BASE_CONFIGS)
+def test_eval_gradients_match_reference(name):
+    z, kw, cfg, sd, model = build(name)
+    model.eval()  # dropout inactive: deterministic gradients (SURVEY §7 'Dropout')
+    kind = "randn"
+    x1, x2, labels = t(z[f"{kind}/eeg1"]).to(DEV), t(z[f"{kind}/eeg2"]).to(DEV), t(z["labels"]).to(DEV)
+    out = model(x1, x2, labels)
+    loss = out["loss_ce"]
+    loss.backward()
+    torch.cuda.synchronize()
+    names = [str(n) for n in z[f"{kind}/grad/names"]]
+    norms = z[f"{kind}/grad/norms"]
+    params = dict(model.named_parameters())
+    bad = []
+    for n, ref in zip(names, norms):
+        g = params[n].grad
+        assert g is not None and torch.isfinite(g).all(), n
+        got = float(g.norm())
+        if abs(got - ref) > 5e-2 * ref + 2e-4:
+            bad.append((n, got, float(ref)))
+    assert not bad, bad[:10]
+    for key in z.files:
+        if key.startswith(f"{kind}/grad/full/"):
+            n = key.split("/full/")[1]
+            ref = torch.from_numpy(z[key]).double()
+            got = params[n].grad.cpu().double()
+            fro = float((got - ref).norm() / ref.norm().clamp_min(1e-12))
+            assert fro < 5e-2, (n, fro)
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters())))
+    assert abs(gn - float(z[f"{kind}/grad/global_norm"])) < 3e-2 * float(z[f"{kind}/grad/global_norm"])
+
+
+@pytest.mark.parametrize("name", ["cfg3_xattn", "tiny_a1"])
+def test_native_step_matches_reference(name):
+    """forward + backward + clip(1.0) + AdamW(1e-4, .01) entirely in HIP vs the reference's one step."""
+    z, kw, cfg, sd, model = build(name)
+    model.eval()
+    kind = "randn"
+    x1, x2, labels = t(z[f"{kind}/eeg1"]).to(DEV), t(z[f"{kind}/eeg2"]).to(DEV), t(z["labels"]).to(DEV)
+    eng = model.engine(x1.shape[0], x1.shape[2], x1.device)
+    opt = HipAdamW(model, lr=1e-4, weight_decay=0.01)
+    opt.begin_step(eng, seed=1)
+    eng.forward(x1, x2, labels, train=False)
+    eng.backward(gloss=torch.ones(1, device=DEV))
+    opt.step(eng)
+    torch.cuda.synchronize()
+    st = eng.read_state()
+    ref_norm = float(z[f"{kind}/step/total_norm"])
+    assert abs(st.grad_norm - ref_norm) < 3e-2 * ref_norm
+    names = [str(n) for n in z[f"{kind}/grad/names"]]
+    params = dict(model.named_parameters())
+    l2 = np.array([float(params[n].detach().double().norm()) for n in names])
+    np.testing.assert_allclose(l2, z[f"{kind}/step/param_l2"], rtol=1e-4, atol=1e-4)
+    delta = np.array([float((params[n].detach().cpu() - sd[n]).double().norm()) for n in names])
+    np.testing.assert_allclose(delta, z[f"{kind}/step/delta_l2"], rtol=0.1, atol=2e-5)
+
+
+def test_train_mode_step_runs_and_learns():
+    """Train mode (dropout on): finite losses, masks change with the seed, and a few native steps on a fixed
+    batch reduce the loss."""
+    torch.manual_seed(0)
+    kw = dict(in_channels=8, num_classes=3, max_len=256, use_spectrogram=False, use_ibs=False, use_cross_attention=True)
+    model = DualEEGTransformer(**kw).to(DEV)
+    model.train()
+    g = torch.Generator().manual_seed(1)
+    B = 16
+    x1 = torch.randn(B, 8, 1024, generator=g).to(DEV)
+    x2 = torch.randn(B, 8, 1024, generator=g).to(DEV)
+    labels = (torch.arange(B) % 3).to(DEV)
+    x1[labels == 1] += 0.5 * torch.sin(torch.arange(1024, device=DEV) * 0.3)
+    x1[labels == 2] -= 0.5 * torch.sin(torch.arange(1024, device=DEV) * 0.1)
+    eng = model.engine(B, 1024, x1.device)
+    opt = HipAdamW(model, lr=3e-4)
+    losses = []
+    for step in range(30):
+        opt.begin_step(eng, seed=100 + step)
+        eng.forward(x1, x2, labels, train=True)
+        eng.backward(gloss=torch.ones(1, device=DEV))
+        opt.step(eng)
+        losses.append(float(eng.a["loss"]))
+    assert all(np.isfinite(losses)), losses
+    assert np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.05, losses
+    # same seed -> identical forward; different seed -> different dropout masks
+    opt.begin_step(eng, seed=7)
+    eng.forward(x1, x2, labels, train=True)
+    a = eng.a["logits"].clone()
+    eng.forward(x1, x2, labels, train=True)
+    b = eng.a["logits"].clone()
+    eng.set_state(seed=8, lr=0.0, step=1)
+    eng.forward(x1, x2, labels, train=True)
+    c = eng.a["logits"].clone()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_autograd_loop_like_reference():
+    """The reference's own loop shape (train_art.py:175-222): zero_grad / forward / loss / backward /
+    clip_grad_norm_ / torch AdamW on model.parameters() works against the HIP module."""
+    torch.manual_seed(0)
+    kw = dict(in_channels=8, num_classes=2, max_len=256, use_spectrogram=False, use_ibs=False)
+    model = DualEEGTransformer(**kw).to(DEV)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01)
+    g = torch.Generator().manual_seed(1)
+    x1, x2 = torch.randn(8, 8, 1024, generator=g).to(DEV), torch.randn(8, 8, 1024, generator=g).to(DEV)
+    labels = (torch.arange(8) % 2).to(DEV)
+    before = model.classifier[3].weight.detach().clone()
+    for _ in range(2):
+        opt.zero_grad()
+        out = model(x1, x2, labels)
+        loss = out["loss_ce"] + 0.1 * model.compute_symmetry_loss(out["cls1"], out["cls2"])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        opt.step()
+    assert torch.isfinite(loss)
+    assert not torch.equal(before, model.classifier[3].weight.detach())
+
+
+def test_cpu_tensors_are_refused():
+    model = DualEEGTransformer(in_channels=8, max_len=256, use_spectrogram=False, use_ibs=False)
+    with pytest.raises(L.EgError):
+        model(torch.zeros(2, 8, 1024), torch.zeros(2, 8, 1024))
