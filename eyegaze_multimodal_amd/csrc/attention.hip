@@ -319,6 +319,128 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Exact-fp32 attention (EG_F32): the parity path.  One workgroup per (sample, head), one thread per query
+// (forward, dQ) or per key (dK, dV); Q/K/V/dO head slices live in LDS and are read as broadcasts.
+// Plain fmaf chains, no MFMA: this path exists to pin the orchestration bit-tight against the fp32 oracle.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot32(const float* a, const float* b) {
+  float s = 0.f;
+#pragma unroll
+  for (int d = 0; d < 32; ++d) s = fmaf(a[d], b[d], s);
+  return s;
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
+                                                           float* __restrict__ lse, int NB, int S, int H, int kv_shift,
+                                                           DropCfg dc, const eg_step_state* st) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Kl = (float*)smem;       // [S][32]
+  float* Vl = Kl + S * 32;        // [S][32]
+  const int pid = blockIdx.x, b = pid / H, h = pid % H, bk = (b + kv_shift) % NB, D = H * 32;
+  const long long ld = 3ll * D;
+  for (int i = threadIdx.x; i < S * 32; i += blockDim.x) {
+    const int r = i >> 5, d = i & 31;
+    Kl[i] = qkv[((long long)bk * S + r) * ld + D + h * 32 + d];
+    Vl[i] = qkv[((long long)bk * S + r) * ld + 2 * D + h * 32 + d];
+  }
+  __syncthreads();
+  const int q = threadIdx.x;
+  if (q >= S) return;
+  float qv[32], o[32];
+#pragma unroll
+  for (int d = 0; d < 32; ++d) { qv[d] = qkv[((long long)b * S + q) * ld + h * 32 + d]; o[d] = 0.f; }
+  float mx = -INFINITY;
+  for (int k = 0; k < S; ++k) mx = fmaxf(mx, dot32(qv, Kl + k * 32) * kScale);
+  float sum = 0.f;
+  for (int k = 0; k < S; ++k) sum += expf(dot32(qv, Kl + k * 32) * kScale - mx);
+  const float inv = 1.0f / sum;
+  uint32_t seed_lo = 0, seed_hi = 0;
+  if (dc.thresh) { seed_lo = st->seed_lo; seed_hi = st->seed_hi; }
+  const uint32_t rowidx = (uint32_t)((b * H + h) * S + q) * (uint32_t)S;
+  for (int k = 0; k < S; ++k) {
+    float p = expf(dot32(qv, Kl + k * 32) * kScale - mx) * inv;
+    if (dc.thresh) p = eg_dropout(p, dc, seed_lo, seed_hi, rowidx + (uint32_t)k);
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = fmaf(p, Vl[k * 32 + d], o[d]);
+  }
+  lse[((long long)b * H + h) * S + q] = mx + logf(sum);
+#pragma unroll
+  for (int d = 0; d < 32; ++d) ctx[((long long)b * S + q) * D + h * 32 + d] = o[d];
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                           const float* __restrict__ dctx, const float* __restrict__ lse,
+                                                           float* __restrict__ dqkv, int NB, int S, int H, int kv_shift,
+                                                           DropCfg dc, const eg_step_state* st) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Ql = (float*)smem;        // [S][32]
+  float* Kl = Ql + S * 32;
+  float* Vl = Kl + S * 32;
+  float* Dl = Vl + S * 32;         // dO
+  float* lsel = Dl + S * 32;       // [S]
+  float* dl = lsel + S;            // [S]  delta = rowsum(dO * O)
+  const int pid = blockIdx.x, b = pid / H, h = pid % H, bk = (b + kv_shift) % NB, D = H * 32;
+  const long long ld = 3ll * D;
+  for (int i = threadIdx.x; i < S * 32; i += blockDim.x) {
+    const int r = i >> 5, d = i & 31;
+    Ql[i] = qkv[((long long)b * S + r) * ld + h * 32 + d];
+    Kl[i] = qkv[((long long)bk * S + r) * ld + D + h * 32 + d];
+    Vl[i] = qkv[((long long)bk * S + r) * ld + 2 * D + h * 32 + d];
+    Dl[i] = dctx[((long long)b * S + r) * D + h * 32 + d];
+  }
+  for (int r = threadIdx.x; r < S; r += blockDim.x) {
+    lsel[r] = lse[((long long)b * H + h) * S + r];
+    float s = 0.f;
+    for (int d = 0; d < 32; ++d)
+      s = fmaf(dctx[((long long)b * S + r) * D + h * 32 + d], ctx[((long long)b * S + r) * D + h * 32 + d], s);
+    dl[r] = s;
+  }
+  __syncthreads();
+  uint32_t seed_lo = 0, seed_hi = 0;
+  if (dc.thresh) { seed_lo = st->seed_lo; seed_hi = st->seed_hi; }
+  const uint32_t headidx = (uint32_t)((b * H + h) * S);
+  const int t = threadIdx.x;
+  if (t < S) {
+    // thread = query t: dQ
+    float acc[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) acc[d] = 0.f;
+    for (int k = 0; k < S; ++k) {
+      const float p = expf(dot32(Ql + t * 32, Kl + k * 32) * kScale - lsel[t]);
+      float dp = dot32(Dl + t * 32, Vl + k * 32);
+      if (dc.thresh) dp = eg_dropout(dp, dc, seed_lo, seed_hi, (headidx + (uint32_t)t) * (uint32_t)S + (uint32_t)k);
+      const float ds = p * (dp - dl[t]);
+#pragma unroll
+      for (int d = 0; d < 32; ++d) acc[d] = fmaf(ds, Kl[k * 32 + d], acc[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < 32; ++d) dqkv[((long long)b * S + t) * ld + h * 32 + d] = acc[d] * kScale;
+    // thread = key t: dK, dV
+    float ak[32], av[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) { ak[d] = 0.f; av[d] = 0.f; }
+    for (int q = 0; q < S; ++q) {
+      const float p = expf(dot32(Ql + q * 32, Kl + t * 32) * kScale - lsel[q]);
+      const float dpr = dot32(Dl + q * 32, Vl + t * 32);
+      float m = 1.0f;
+      if (dc.thresh) m = eg_dropout(1.0f, dc, seed_lo, seed_hi, (headidx + (uint32_t)q) * (uint32_t)S + (uint32_t)t);
+      const float pd = p * m, ds = p * (dpr * m - dl[q]);
+#pragma unroll
+      for (int d = 0; d < 32; ++d) {
+        av[d] = fmaf(pd, Dl[q * 32 + d], av[d]);
+        ak[d] = fmaf(ds, Ql[q * 32 + d], ak[d]);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 32; ++d) {
+      dqkv[((long long)bk * S + t) * ld + D + h * 32 + d] = ak[d] * kScale;
+      dqkv[((long long)bk * S + t) * ld + 2 * D + h * 32 + d] = av[d];
+    }
+  }
+}
+
 template <int SP>
 int launch_fwd(const void* qkv, void* ctx, float* lse, int NB, int S, int H, int kv_shift, DropCfg dc,
                const eg_step_state* st, hipStream_t s) {
@@ -348,7 +470,7 @@ static int attn_check(const char* who, int NB, int S, int H, int kv_shift, int d
   EG_CHECK(NB > 0 && S > 0 && H > 0, "%s: bad shape NB=%d S=%d H=%d", who, NB, S, H);
   EG_CHECK(S <= 160, "%s: S=%d exceeds the register-resident limit of 160", who, S);
   EG_CHECK(kv_shift >= 0 && kv_shift < NB, "%s: kv_shift=%d out of range", who, kv_shift);
-  EG_CHECK(dtype == EG_BF16, "%s: only EG_BF16 is implemented for the attention core (dtype=%d)", who, dtype);
+  EG_CHECK(dtype == EG_BF16 || dtype == EG_F32, "%s: bad dtype %d", who, dtype);
   EG_CHECK(p >= 0.f && p < 1.f && (p == 0.f || st), "%s: dropout p=%f needs a step state", who, (double)p);
   EG_CHECK((long long)NB * H * S * S < (1ll << 32), "%s: NB*H*S*S exceeds the 32-bit dropout index", who);
   return 0;
@@ -360,6 +482,12 @@ extern "C" int eg_attention_fwd(const void* qkv, void* ctx, float* lse, int NB, 
   if (attn_check("eg_attention_fwd", NB, S, H, kv_shift, dtype, drop_p, state)) return 1;
   DropCfg dc = make_drop(drop_p, drop_site);
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == EG_F32) {
+    hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(NB * H), dim3(256), 2 * S * 32 * 4, s, (const float*)qkv, (float*)ctx, lse,
+                       NB, S, H, kv_shift, dc, state);
+    EG_LAUNCH_CHECK("attention_fwd_f32");
+    return 0;
+  }
   if (S <= 96) launch_fwd<96>(qkv, ctx, lse, NB, S, H, kv_shift, dc, state, s);
   else if (S <= 128) launch_fwd<128>(qkv, ctx, lse, NB, S, H, kv_shift, dc, state, s);
   else launch_fwd<160>(qkv, ctx, lse, NB, S, H, kv_shift, dc, state, s);
@@ -374,6 +502,18 @@ extern "C" int eg_attention_bwd(const void* qkv, const void* ctx, const void* dc
   if (attn_check("eg_attention_bwd", NB, S, H, kv_shift, dtype, drop_p, state)) return 1;
   DropCfg dc = make_drop(drop_p, drop_site);
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == EG_F32) {
+    const int lds = (4 * S * 32 + 2 * S) * 4;
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute((const void*)attn_bwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (4 * 160 * 32 + 320) * 4);
+      attr = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_f32_kernel, dim3(NB * H), dim3(256), lds, s, (const float*)qkv, (const float*)ctx,
+                       (const float*)dctx, lse, (float*)dqkv, NB, S, H, kv_shift, dc, state);
+    EG_LAUNCH_CHECK("attention_bwd_f32");
+    return 0;
+  }
   if (S <= 96) launch_bwd<96>(qkv, ctx, dctx, lse, dqkv, NB, S, H, kv_shift, dc, state, s);
   else if (S <= 128) launch_bwd<128>(qkv, ctx, dctx, lse, dqkv, NB, S, H, kv_shift, dc, state, s);
   else launch_bwd<160>(qkv, ctx, dctx, lse, dqkv, NB, S, H, kv_shift, dc, state, s);

@@ -65,7 +65,8 @@ def test_gemm_nt_plain(dtype, shape):
     bias = torch.randn(N, generator=g)
     res = torch.randn(M, N, generator=g).to(DT[dtype])
     ref = torch.relu(A.double() @ W.double().T + bias.double()) + res.double()
-    out = gemm_nt(A.to(DEV), W.to(DEV), M, N, K, dtype, bias=bias.to(DEV), residual=res.to(DEV), act=L.ACT_RELU)
+    Ad, Wd, bd, rd = A.to(DEV), W.to(DEV), bias.to(DEV), res.to(DEV)
+    out = gemm_nt(Ad, Wd, M, N, K, dtype, bias=bd, residual=rd, act=L.ACT_RELU)
     torch.testing.assert_close(out.cpu().double(), ref, **tol(dtype))
 
 
@@ -76,7 +77,8 @@ def test_gemm_nt_asymmetric_identity(dtype):
     M = 128
     A = torch.eye(M, K).to(DT[dtype])
     W = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125).to(DT[dtype])
-    out = gemm_nt(A.to(DEV), W.to(DEV), M, N, K, dtype)
+    Ad, Wd = A.to(DEV), W.to(DEV)
+    out = gemm_nt(Ad, Wd, M, N, K, dtype)
     torch.testing.assert_close(out.cpu().float(), W.float().T.contiguous(), rtol=0, atol=0)
 
 
@@ -95,13 +97,14 @@ def test_conv1d_as_grouped_gemm(dtype):
     Tp = max(T + 2 * pad, s * (T1 - 1) + K0 // Cc + 1)
     Tp = (Tp + 7) // 8 * 8
     xt = torch.zeros(NB, Tp, Cc, device=DEV, dtype=DT[dtype])
-    call("eg_window_pack", ptr(x.to(DEV)), ptr(xt), NB, Cc, T, Cc, pad, Tp, dtype, 0)
+    xdev, wdev, bdev = x.to(DEV), w.to(DEV), b.to(DEV)
+    call("eg_window_pack", ptr(xdev), ptr(xt), NB, Cc, T, Cc, pad, Tp, dtype, 0)
     ref_xt = torch.zeros(NB, Tp, Cc)
     ref_xt[:, pad:pad + T] = x.transpose(1, 2)
     torch.testing.assert_close(xt.cpu().float(), ref_xt.to(DT[dtype]).float(), rtol=0, atol=0)
     wp = torch.zeros(dm, K0, device=DEV, dtype=DT[dtype])
-    call("eg_pack_conv_weight", ptr(w.to(DEV)), ptr(wp), dm, Cc, k, Cc, K0, dtype, 0)
-    out = gemm_nt(xt, wp, NB * T1, dm, K0, dtype, a=rowmap(s * Cc, Tp * Cc, T1), bias=b.to(DEV), act=L.ACT_RELU)
+    call("eg_pack_conv_weight", ptr(wdev), ptr(wp), dm, Cc, k, Cc, K0, dtype, 0)
+    out = gemm_nt(xt, wp, NB * T1, dm, K0, dtype, a=rowmap(s * Cc, Tp * Cc, T1), bias=bdev, act=L.ACT_RELU)
     xr = x.to(DT[dtype]).double()
     wr = w.to(DT[dtype]).double()
     ref = torch.relu(torch.nn.functional.conv1d(xr, wr, b.double(), stride=s, padding=pad)).transpose(1, 2).reshape(NB * T1, dm)
@@ -133,7 +136,8 @@ def test_gemm_nt_dropout_and_gate(dtype):
     stats = torch.zeros(M, 2, device=DEV)
     gam = torch.ones(N, device=DEV)
     y = torch.zeros_like(x)
-    call("eg_layernorm_fwd", ptr(x), ptr(gam), ptr(torch.zeros(N, device=DEV)), ptr(y), ptr(stats), M, N, dtype, 0)
+    bet = torch.zeros(N, device=DEV)
+    call("eg_layernorm_fwd", ptr(x), ptr(gam), ptr(bet), ptr(y), ptr(stats), M, N, dtype, 0)
     dx, dxd = torch.zeros_like(x), torch.zeros_like(x)
     part = torch.zeros(64 * 2 * N, device=DEV)
     dyr = torch.randn(M, N, generator=g).to(DT[dtype]).to(DEV)
@@ -158,9 +162,8 @@ def test_gemm_tn(dtype, shape):
     for splits in (1, 7):
         part = torch.zeros(splits * N * K, device=DEV)
         d = GemmTNDesc()
-        d.dY, d.X, d.partial = ptr(dY.to(DEV)), ptr(X.to(DEV)), ptr(part)
         dYd, Xd = dY.to(DEV), X.to(DEV)
-        d.dY, d.X = ptr(dYd), ptr(Xd)
+        d.dY, d.X, d.partial = ptr(dYd), ptr(Xd), ptr(part)
         d.y, d.x = rowmap(N), rowmap(K)
         d.M, d.N, d.K, d.splits, d.dtype = M, N, K, splits, dtype
         call("eg_gemm_tn", C.byref(d), 0)
@@ -186,7 +189,8 @@ def test_layernorm(dtype, D):
     gam, bet = torch.randn(D, generator=g) * 0.1 + 1, torch.randn(D, generator=g) * 0.1
     dy = torch.randn(M, D, generator=g).to(DT[dtype])
     xd, y, stats = x.to(DEV), torch.zeros(M, D, device=DEV, dtype=DT[dtype]), torch.zeros(M, 2, device=DEV)
-    call("eg_layernorm_fwd", ptr(xd), ptr(gam.to(DEV)), ptr(bet.to(DEV)), ptr(y), ptr(stats), M, D, dtype, 0)
+    gamd, betd = gam.to(DEV), bet.to(DEV)  # keep device operands alive across the asynchronous launch
+    call("eg_layernorm_fwd", ptr(xd), ptr(gamd), ptr(betd), ptr(y), ptr(stats), M, D, dtype, 0)
     xr = x.double().requires_grad_(True)
     gr, br = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
     ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
@@ -196,7 +200,6 @@ def test_layernorm(dtype, D):
     dx = torch.zeros_like(xd)
     nblk = 32
     part = torch.zeros(nblk * 2 * D, device=DEV)
-    gamd = gam.to(DEV)
     dyd = dy.to(DEV)
     call("eg_layernorm_bwd", ptr(dyd), ptr(xd), ptr(stats), ptr(gamd), ptr(dx), 0, ptr(part), nblk, M, D, dtype, 0.0, 0, 0.0,
          0, 0, 0)
@@ -249,6 +252,27 @@ def test_attention_fwd_bwd(S, kv_shift):
     assert err < 3e-2 * max(1.0, scale), (err, scale)
     # relative Frobenius error is the sharper statement
     assert ((got - ref).norm() / ref.norm()).item() < 2e-2
+
+
+@pytest.mark.parametrize("S,kv_shift", [(65, 0), (115, 3), (139, 0)])
+def test_attention_f32_exact(S, kv_shift):
+    """EG_F32 attention (plain fmaf chains) against fp64: the tight-parity path."""
+    NB, H = 4, 2
+    D = H * 32
+    g = torch.Generator().manual_seed(S + 1)
+    qkv = torch.randn(NB * S, 3 * D, generator=g)
+    dO = torch.randn(NB * S, D, generator=g)
+    qkvd, ctx, lse = qkv.to(DEV), torch.zeros(NB * S, D, device=DEV), torch.zeros(NB, H, S, device=DEV)
+    call("eg_attention_fwd", ptr(qkvd), ptr(ctx), ptr(lse), NB, S, H, kv_shift, L.EG_F32, 0.0, 0, 0, 0)
+    qr = qkv.double().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(qr, NB, S, H, kv_shift)
+    o_ref.backward(dO.double())
+    dqkv, dOd = torch.zeros_like(qkvd), dO.to(DEV)
+    call("eg_attention_bwd", ptr(qkvd), ptr(ctx), ptr(dOd), ptr(lse), ptr(dqkv), NB, S, H, kv_shift, L.EG_F32, 0.0, 0, 0, 0)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(ctx.cpu().double(), o_ref.detach(), rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(lse.cpu().double(), lse_ref.detach(), rtol=1e-6, atol=2e-6)
+    torch.testing.assert_close(dqkv.cpu().double(), qr.grad, rtol=1e-4, atol=1e-5)
 
 
 def test_attention_dropout_consistency():
@@ -346,4 +370,4 @@ def test_rejects_bad_arguments():
     with pytest.raises(L.EgError):
         call("eg_attention_fwd", ptr(A), ptr(A), ptr(A), 1, 200, 1, 0, L.EG_BF16, 0.0, 0, 0, 0)  # S too long
     with pytest.raises(L.EgError):
-        call("eg_attention_fwd", ptr(A), ptr(A), ptr(A), 1, 8, 1, 0, L.EG_F32, 0.0, 0, 0, 0)  # dtype not implemented
+        call("eg_attention_fwd", ptr(A), ptr(A), ptr(A), 1, 8, 1, 0, 7, 0.0, 0, 0, 0)  # unknown dtype
