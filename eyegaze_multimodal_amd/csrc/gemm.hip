@@ -349,20 +349,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN<T> p) {
     }
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, long long n,
-                                       int splits, long long sstride, int accumulate) {
-  const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i4 >= n) return;
+// out[i] = sum_s partial[s*sstride + i].  256 threads = 8 float4 columns x 32 split lanes, so short outputs
+// (bias / LayerNorm-gain gradients, n ~ 256) still spread their `splits` loads over many lanes.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                              long long n, int splits, long long sstride, int accumulate) {
+  __shared__ f32x4 red[32][8];
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const long long i4 = ((long long)blockIdx.x * 8 + tx) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i4 + 4 <= n) {
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < splits; ++k) s += *(const f32x4*)(partial + (size_t)k * sstride + i4);
-    if (accumulate) s += *(const f32x4*)(out + i4);
-    *(f32x4*)(out + i4) = s;
-  } else {
-    for (long long i = i4; i < n; ++i) {
-      float s = accumulate ? out[i] : 0.f;
-      for (int k = 0; k < splits; ++k) s += partial[(size_t)k * sstride + i];
-      out[i] = s;
+    for (int k = ty; k < splits; k += 32) s += *(const f32x4*)(partial + (size_t)k * sstride + i4);
+  } else if (i4 < n) {
+    for (int k = ty; k < splits; k += 32)
+      for (int e = 0; e < (int)(n - i4); ++e) s[e] += partial[(size_t)k * sstride + i4 + e];
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i4 < n) {
+    f32x4 t = red[0][tx];
+#pragma unroll
+    for (int r = 1; r < 32; ++r) t += red[r][tx];
+    if (i4 + 4 <= n) {
+      if (accumulate) t += *(const f32x4*)(out + i4);
+      *(f32x4*)(out + i4) = t;
+    } else {
+      for (int e = 0; e < (int)(n - i4); ++e) out[i4 + e] = (accumulate ? out[i4 + e] : 0.f) + t[e];
     }
   }
 }
@@ -504,8 +515,8 @@ extern "C" int eg_reduce_partials(const float* partial, float* out, int64_t n, i
   EG_CHECK(partial && out && n > 0 && splits > 0 && split_stride >= n, "eg_reduce_partials: bad arguments");
   EG_CHECK(((uintptr_t)partial | (uintptr_t)out) % 16 == 0 && split_stride % 4 == 0,
            "eg_reduce_partials: 16-B alignment (split_stride %% 4 == 0)");
-  const long long nthreads = (n + 3) / 4;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0,
+  const long long ncol = (n + 3) / 4;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((ncol + 7) / 8)), dim3(256), 0,
                      (hipStream_t)stream, partial, out, (long long)n, splits, (long long)split_stride, accumulate);
   EG_LAUNCH_CHECK("reduce_partials");
   return 0;

@@ -127,6 +127,7 @@ class Engine:
         self.M = self.NB * self.S
         self.fp: FlatParams = model._flat
         self.stream = 0
+        self.probes = {}   # tag -> (start_event, end_event) recorded around that launch (bench.py roofline probe)
         self._alloc()
         self.packed_version = -1
 
@@ -263,7 +264,15 @@ class Engine:
     # thin wrappers
     # ------------------------------------------------------------------------------------------
     def gemm(self, A, W, Cout, M, N, K, *, a=None, c=None, r=None, p=None, ldw=None, bias=0, residual=0, gate=0,
-             out_pre=0, act=0, drop1=(0.0, 0), drop2=(0.0, 0), gate_scale=1.0):
+             out_pre=0, act=0, drop1=(0.0, 0), drop2=(0.0, 0), gate_scale=1.0, tag=None):
+        probe = self.probes.get(tag) if tag else None
+        if probe:
+            probe[0].record(torch.cuda.current_stream(self.device))
+        self._gemm(A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale)
+        if probe:
+            probe[1].record(torch.cuda.current_stream(self.device))
+
+    def _gemm(self, A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale):
         dsc = GemmDesc()
         dsc.A, dsc.W, dsc.C = A, W, Cout
         dsc.bias, dsc.residual, dsc.gate, dsc.out_pre = bias or None, residual or None, gate or None, out_pre or None
@@ -282,7 +291,7 @@ class Engine:
     def wgrad(self, dY, X, out_w, M, N, K, *, y=None, x=None, out_b=0, conv=None, split_out=None):
         """dW = dY^T X (+ db = colsum dY).  split_out: list of (grad_ptr, row0, rows) for fused weights."""
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        splits = max(1, min((M + 255) // 256, (768 + tiles - 1) // tiles, self.tn_cap // (N * K)))
+        splits = max(1, min((M + 127) // 128, (512 + tiles - 1) // tiles, self.tn_cap // (N * K)))
         dsc = GemmTNDesc()
         dsc.dY, dsc.X, dsc.partial = dY, X, ptr(self.g["partial"])
         dsc.y = y or rowmap(N)
@@ -299,7 +308,7 @@ class Engine:
         else:
             call("eg_reduce_partials", pp, out_w, N * K, splits, N * K, 0, self.stream)
         if out_b:
-            nblk = min(256, (M + 63) // 64)
+            nblk = min(128, (M + 63) // 64)
             call("eg_colsum", dY, dsc.y, M, N, ptr(self.g["cspart"]), nblk, self.dtype, self.stream)
             if isinstance(out_b, (list, tuple)):
                 for gp, col0, cols in out_b:
@@ -383,7 +392,7 @@ class Engine:
         self.gemm(ptr(a["h0pad"]), ptr(w["conv1"]), ptr(a["x0"]) + self.off * d * es, NB * self.T2, d, self.k * d,
                   a=rowmap(self.s * d, self.R0 * d, self.T2), c=rowmap(d, S * d, self.T2),
                   r=rowmap(d, 0, self.T2), p=rowmap(d), bias=fp.p_ptr("temporal_conv.convs.1.bias"), act=L.ACT_RELU,
-                  drop1=(p01, SITE_CONV1), residual=ptr(w["pos"]) + self.off * d * es, out_pre=ptr(a["h1"]))
+                  drop1=(p01, SITE_CONV1), residual=ptr(w["pos"]) + self.off * d * es, out_pre=ptr(a["h1"]), tag="conv1_fwd")
         # CLS rows (D:1157) + pos row 0
         call("eg_rows_bcast_f32", fp.p_ptr("cls_token"), fp.p_ptr("pos_embed.pos_embed.weight"), ptr(a["x0"]), NB, S, d, 1,
              0, 1, self.dtype, st)
