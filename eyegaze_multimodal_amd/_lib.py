@@ -40,12 +40,13 @@ class GemmDesc(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldw", C.c_int32),
                 ("act", C.c_int32), ("dtype", C.c_int32),
                 ("drop1_p", C.c_float), ("drop2_p", C.c_float), ("drop1_site", C.c_uint32), ("drop2_site", C.c_uint32),
-                ("gate_scale", C.c_float)]
+                ("gate_scale", C.c_float), ("a_seg_len", C.c_int32), ("a_seg_stride", C.c_int64)]
 
 
 class GemmTNDesc(C.Structure):
     _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("partial", C.c_void_p), ("y", RowMap), ("x", RowMap),
-                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("splits", C.c_int32), ("dtype", C.c_int32)]
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("splits", C.c_int32), ("dtype", C.c_int32),
+                ("x_tile_stride", C.c_int64)]
 
 
 _P, _I, _L, _F, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
@@ -79,6 +80,20 @@ SIGNATURES = {
     "eg_clip_coef": [_P, _I, _F, _P, _P],
     "eg_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P],
     "eg_fill_f32": [_P, _L, _F, _P],
+    "eg_ibs_analytic": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P, _P, _I, _P],
+    "eg_ibs_pairs": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _I, _P],
+    "eg_ibs_scalar": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _I, _I, _I, _I, _P],
+    "eg_affine_grad": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "eg_ibs_inorm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "eg_gelu_fwd": [_P, _P, _L, _I, _F, _U, _P, _P],
+    "eg_gelu_bwd": [_P, _P, _P, _L, _I, _F, _U, _P, _P],
+    "eg_stft_logmag": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "eg_spec_conv1_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "eg_spec_conv1_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "eg_spec_avgpool_fwd": [_P, _P, _I, _I, _I, _I, _P],
+    "eg_spec_avgpool_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "eg_pack_conv2d_weight": [_P, _P, _I, _I, _I, _I, _P],
+    "eg_unpack_conv2d_wgrad": [_P, _P, _I, _I, _I, _P],
 }
 _lib = None
 

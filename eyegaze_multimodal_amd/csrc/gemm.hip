@@ -20,6 +20,8 @@ struct GemmNT {
   int M, N, K, ldw, act, tiles_n, nblocks;
   DropCfg d1, d2;
   float gate_scale;
+  int seg_tiles;              // K-tiles per A-row segment (0 = one contiguous row)
+  long long seg_stride_bytes; // distance between segments of an A row
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -103,6 +105,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT<T> p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / (128 / (int)sizeof(T));
+  // A rows may consist of several equally long segments (2-D convolution windows): K-tile kt starts at koff(kt)
+  auto koff = [&](int kt) -> size_t {
+    if (p.seg_tiles <= 0) return (size_t)kt * 128;
+    const int sg = kt / p.seg_tiles;
+    return (size_t)sg * (size_t)p.seg_stride_bytes + (size_t)(kt - sg * p.seg_tiles) * 128;
+  };
   u32x4 ra[4], rw[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -119,9 +127,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT<T> p) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
     if (more) {
+      const size_t ka = koff(kt + 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        ra[i] = *(const u32x4*)(ap[i] + (size_t)(kt + 1) * 128);
+        ra[i] = *(const u32x4*)(ap[i] + ka);
         rw[i] = *(const u32x4*)(wp[i] + (size_t)(kt + 1) * 128);
       }
     }
@@ -207,6 +216,7 @@ struct GemmTN {
   const T* dY; const T* X; float* partial;
   RowMap y, x;
   int M, N, K, splits, rows_per_split, tiles_k, tiles_nk;
+  long long x_tile_stride;  // elements between consecutive 128-column tiles of an X row (128 = contiguous)
 };
 
 __device__ __forceinline__ int tn_swz(int r) { return (((r & 3) | ((r >> 1) & 4)) << 1); }
@@ -289,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN<T> p) {
   const int n0 = (t / p.tiles_k) * 128, k0 = (t % p.tiles_k) * 128;
   const int mbeg = split * p.rows_per_split;
   const int mend = min(p.M, mbeg + p.rows_per_split);
+  const long long xk0 = (long long)(t % p.tiles_k) * p.x_tile_stride;
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN<T> p) {
       ry[i] = z;
       rx[i] = z;
       if (rv && n0 + ch * EPC < p.N) ry[i] = *(const u32x4*)(p.dY + row_off(p.y, m) + n0 + ch * EPC);
-      if (rv && k0 + ch * EPC < p.K) rx[i] = *(const u32x4*)(p.X + row_off(p.x, m) + k0 + ch * EPC);
+      if (rv && k0 + ch * EPC < p.K) rx[i] = *(const u32x4*)(p.X + row_off(p.x, m) + xk0 + ch * EPC);
     }
   };
   auto store_tile = [&](char* buf) {
@@ -450,6 +461,8 @@ static int launch_gemm_nt(const eg_gemm_desc* d, hipStream_t s) {
   p.d1 = make_drop(d->drop1_p, d->drop1_site);
   p.d2 = make_drop(d->drop2_p, d->drop2_site);
   p.gate_scale = d->gate_scale == 0.f ? 1.0f : d->gate_scale;
+  p.seg_tiles = d->a_seg_len > 0 ? d->a_seg_len / (128 / (int)sizeof(T)) : 0;
+  p.seg_stride_bytes = (long long)d->a_seg_stride * (long long)sizeof(T);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)gemm_nt_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
@@ -473,6 +486,8 @@ extern "C" int eg_gemm_nt(const eg_gemm_desc* d, void* stream) {
   EG_CHECK(d->c.row_stride % 8 == 0 && d->c.group_stride % 8 == 0, "eg_gemm_nt: C rows must be 8-element aligned");
   EG_CHECK(!d->residual || (d->r.row_stride % 8 == 0 && d->r.group_stride % 8 == 0), "eg_gemm_nt: residual rows");
   EG_CHECK(!d->out_pre || (d->p.row_stride % 8 == 0 && d->p.group_stride % 8 == 0), "eg_gemm_nt: out_pre rows");
+  EG_CHECK(d->a_seg_len == 0 || (d->a_seg_len % bk == 0 && d->K % d->a_seg_len == 0 && d->a_seg_stride % al == 0),
+           "eg_gemm_nt: segmented A rows need a_seg_len (=%d) to be a multiple of %d dividing K", d->a_seg_len, bk);
   EG_CHECK((d->drop1_p == 0.f && d->drop2_p == 0.f) || d->state, "eg_gemm_nt: dropout needs a step state");
   EG_CHECK(d->drop1_p >= 0.f && d->drop1_p < 1.f && d->drop2_p >= 0.f && d->drop2_p < 1.f, "eg_gemm_nt: dropout p");
   EG_CHECK((long long)d->M * d->N < (1ll << 32), "eg_gemm_nt: M*N exceeds the 32-bit dropout index");
@@ -491,6 +506,7 @@ static int launch_gemm_tn(const eg_gemm_tn_desc* d, hipStream_t s) {
   p.rows_per_split = (rps + 31) / 32 * 32;
   p.tiles_k = (d->K + 127) / 128;
   p.tiles_nk = p.tiles_k * ((d->N + 127) / 128);
+  p.x_tile_stride = d->x_tile_stride > 0 ? d->x_tile_stride : 128;
   const int lds = 4 * 32 * TNCfg<T>::ROWB;
   hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(p.tiles_nk * d->splits), dim3(256), lds, s, p);
   EG_LAUNCH_CHECK("gemm_tn");
@@ -506,6 +522,7 @@ extern "C" int eg_gemm_tn(const eg_gemm_tn_desc* d, void* stream) {
   EG_CHECK(d->y.row_stride % al == 0 && d->y.group_stride % al == 0 && d->x.row_stride % al == 0 &&
                d->x.group_stride % al == 0, "eg_gemm_tn: rows must be 16-B aligned");
   EG_CHECK(((uintptr_t)d->dY | (uintptr_t)d->X | (uintptr_t)d->partial) % 16 == 0, "eg_gemm_tn: alignment");
+  EG_CHECK(d->x_tile_stride == 0 || (d->x_tile_stride % al == 0 && d->K % 128 == 0), "eg_gemm_tn: x_tile_stride needs K %% 128 == 0");
   hipStream_t s = (hipStream_t)stream;
   return d->dtype == EG_BF16 ? launch_gemm_tn<bf16_t>(d, s) : launch_gemm_tn<float>(d, s);
 }

@@ -1,0 +1,550 @@
+// Signal-processing front ends that feed extra tokens to the encoder (forward only: their inputs carry no gradient).
+//   * inter-stream synchrony ("IBS") connectivity: per band an FFT-mask band-pass + FFT Hilbert transform, then seven
+//     channel-by-channel reductions over time  (dual_eeg_transformer.py:473-819; scalar variant :178-470)
+//   * STFT log-magnitude image of every channel  (dual_eeg_transformer.py:98-121)
+// FFTs are radix-2 Stockham autosort transforms held entirely in LDS (one workgroup per signal); the pair
+// reductions keep both players' band signals and phases of an 8x8 channel tile in LDS (128 KiB).
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_BANDS = 8;
+struct BandTable {
+  int nbands;
+  float lo[MAX_BANDS], hi[MAX_BANDS];
+};
+
+typedef float2 cf;
+__device__ __forceinline__ cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// in-LDS radix-2 Stockham FFT of length N (power of two), all threads of the block cooperate.
+// x: input/output buffer, y: scratch, tw: table exp(-2 pi i k / N), k < N/2.  inverse => conjugated twiddles, no scaling.
+// Returns the buffer that holds the result (natural order).
+__device__ cf* fft_stockham(cf* x, cf* y, const cf* tw, int N, bool inverse) {
+  int n = N, s = 1;
+  while (n > 1) {
+    const int m = n >> 1;
+    const int tstep = N / n;
+    for (int j = threadIdx.x; j < (N >> 1); j += blockDim.x) {
+      const int p = j / s, q = j - p * s;
+      cf w = tw[p * tstep];
+      if (inverse) w.y = -w.y;
+      const cf a = x[q + s * p], b = x[q + s * (p + m)];
+      y[q + s * (2 * p)] = make_float2(a.x + b.x, a.y + b.y);
+      y[q + s * (2 * p + 1)] = cmul(make_float2(a.x - b.x, a.y - b.y), w);
+    }
+    __syncthreads();
+    cf* t = x; x = y; y = t;
+    n = m;
+    s <<= 1;
+  }
+  return x;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+  return s;
+}
+
+// one block per signal (window, channel):  x [T] -> for every band: band-limited signal xb, instantaneous phase,
+// (mean, 1/(std_unbiased+1e-8)) of xb and of xb^2;  plus the complex spectrum bins [0, nbin) of the raw signal.
+__global__ __launch_bounds__(256) void ibs_analytic_kernel(const float* __restrict__ x, float* __restrict__ xb,
+                                                           float* __restrict__ phase, float* __restrict__ stats,
+                                                           cf* __restrict__ spec, int nsig, int T, float fs, int nbin,
+                                                           BandTable bt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* bufX = (cf*)smem;        // [T] spectrum (kept)
+  cf* bufA = bufX + T;         // [T] work
+  cf* bufB = bufA + T;         // [T] work
+  cf* tw = bufB + T;           // [T/2]
+  __shared__ float red[8];
+  const int sig = blockIdx.x;
+  for (int k = threadIdx.x; k < (T >> 1); k += blockDim.x) {
+    float sn, cs;
+    sincospif(-2.0f * (float)k / (float)T, &sn, &cs);
+    tw[k] = make_float2(cs, sn);
+  }
+  for (int t = threadIdx.x; t < T; t += blockDim.x) bufA[t] = make_float2(x[(size_t)sig * T + t], 0.f);
+  __syncthreads();
+  cf* X = fft_stockham(bufA, bufB, tw, T, false);
+  for (int k = threadIdx.x; k < T; k += blockDim.x) bufX[k] = X[k];
+  __syncthreads();
+  for (int k = threadIdx.x; k < nbin; k += blockDim.x) spec[(size_t)sig * nbin + k] = bufX[k];
+  const float df = fs / (float)T;
+  const float invT = 1.0f / (float)T;
+  for (int b = 0; b < bt.nbands; ++b) {
+    for (int k = threadIdx.x; k < T; k += blockDim.x) {
+      const float f = (float)k * df;
+      float h = 0.f;
+      if (k <= (T >> 1) && f >= bt.lo[b] && f <= bt.hi[b]) h = (k == 0 || k == (T >> 1)) ? 1.f : 2.f;
+      bufA[k] = make_float2(bufX[k].x * h, bufX[k].y * h);
+    }
+    __syncthreads();
+    cf* a = fft_stockham(bufA, bufB, tw, T, true);
+    float s1 = 0.f, s2 = 0.f, s4 = 0.f;
+    const size_t base = ((size_t)b * nsig + sig) * T;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+      const float re = a[t].x * invT, im = a[t].y * invT;
+      xb[base + t] = re;
+      phase[base + t] = atan2f(im, re);
+      const float p = re * re;
+      s1 += re; s2 += p; s4 += p * p;
+    }
+    const float S1 = block_sum(s1, red), S2 = block_sum(s2, red), S4 = block_sum(s4, red);
+    if (threadIdx.x == 0) {
+      const float n = (float)T;
+      const float mx = S1 / n, mp = S2 / n;
+      const float vx = fmaxf((S2 - n * mx * mx) / (n - 1.f), 0.f);
+      const float vp = fmaxf((S4 - n * mp * mp) / (n - 1.f), 0.f);
+      float* st = stats + ((size_t)b * nsig + sig) * 4;
+      st[0] = mx; st[1] = 1.0f / (sqrtf(vx) + 1e-8f);
+      st[2] = mp; st[3] = 1.0f / (sqrtf(vp) + 1e-8f);
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+// grid (B, nbands, tiles_i * tiles_j): 8x8 channel tile of player 1 x player 2.
+// out conn [B, nbands, 7, C, C] in the reference's feature order [PLV, PLI, wPLI, Coherence, Power_Corr, Phase_Diff, Time_Corr]
+__global__ __launch_bounds__(256) void ibs_pairs_kernel(const float* __restrict__ xb, const float* __restrict__ phase,
+                                                        const float* __restrict__ stats, const cf* __restrict__ spec,
+                                                        float* __restrict__ conn, int B, int C, int T, float fs, int nbin,
+                                                        BandTable bt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Tc = min(T, 1024);
+  float* x1 = (float*)smem;       // [8][Tc]
+  float* p1 = x1 + 8 * Tc;
+  float* x2 = p1 + 8 * Tc;
+  float* p2 = x2 + 8 * Tc;
+  const int b = blockIdx.x, band = blockIdx.y;
+  const int tj = (C + 7) / 8;
+  const int i0 = (blockIdx.z / tj) * 8, j0 = (blockIdx.z % tj) * 8;
+  const int nsig = 2 * B * C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[16][8];
+#pragma unroll
+  for (int a = 0; a < 16; ++a)
+#pragma unroll
+    for (int f = 0; f < 8; ++f) acc[a][f] = 0.f;
+  for (int t0 = 0; t0 < T; t0 += Tc) {
+    const int tn = min(Tc, T - t0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 8 * tn; idx += blockDim.x) {
+      const int c = idx / tn, t = idx - c * tn;
+      const int ci = min(i0 + c, C - 1), cj = min(j0 + c, C - 1);
+      const size_t s1 = ((size_t)band * nsig + (size_t)b * C + ci) * T + t0 + t;
+      const size_t s2 = ((size_t)band * nsig + (size_t)(b + B) * C + cj) * T + t0 + t;
+      x1[c * Tc + t] = xb[s1]; p1[c * Tc + t] = phase[s1];
+      x2[c * Tc + t] = xb[s2]; p2[c * Tc + t] = phase[s2];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+      const int pr = wave * 16 + a, ii = pr >> 3, jj = pr & 7;
+      const int ci = min(i0 + ii, C - 1), cj = min(j0 + jj, C - 1);
+      const float* s1 = stats + ((size_t)band * nsig + (size_t)b * C + ci) * 4;
+      const float* s2 = stats + ((size_t)band * nsig + (size_t)(b + B) * C + cj) * 4;
+      const float m1 = s1[0], r1 = s1[1], mp1 = s1[2], rp1 = s1[3];
+      const float m2 = s2[0], r2 = s2[1], mp2 = s2[2], rp2 = s2[3];
+      for (int t = lane; t < tn; t += 64) {
+        const float a1 = x1[ii * Tc + t], a2 = x2[jj * Tc + t];
+        const float d = p1[ii * Tc + t] - p2[jj * Tc + t];
+        float sn, cs;
+        sincosf(d, &sn, &cs);
+        const float sg = sgn(d);
+        const float q1 = a1 * a1, q2 = a2 * a2;
+        const float w = (q1 + q2) * 0.5f;
+        acc[a][0] += cs; acc[a][1] += sn; acc[a][2] += sg; acc[a][3] += sg * w; acc[a][4] += w;
+        acc[a][5] += fabsf(d);
+        acc[a][6] += ((q1 - mp1) * rp1) * ((q2 - mp2) * rp2);
+        acc[a][7] += ((a1 - m1) * r1) * ((a2 - m2) * r2);
+      }
+    }
+  }
+  const float invT = 1.0f / (float)T;
+  const float df = fs / (float)T;
+#pragma unroll
+  for (int a = 0; a < 16; ++a) {
+    const int pr = wave * 16 + a, ii = pr >> 3, jj = pr & 7;
+    float v[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) v[f] = wave_sum(acc[a][f]);
+    // coherence: mean over the T/2+1 rFFT bins of |X1 X2*|^2 / (|X1|^2 |X2|^2 + 1e-8); only in-band bins are non-zero
+    float coh = 0.f;
+    const int ci = min(i0 + ii, C - 1), cj = min(j0 + jj, C - 1);
+    const cf* f1 = spec + ((size_t)b * C + ci) * nbin;
+    const cf* f2 = spec + ((size_t)(b + B) * C + cj) * nbin;
+    for (int k = lane; k < nbin; k += 64) {
+      const float f = (float)k * df;
+      if (f >= bt.lo[band] && f <= bt.hi[band]) {
+        const cf u = f1[k], w = f2[k];
+        const cf xy = cmul(u, make_float2(w.x, -w.y));
+        const float num = xy.x * xy.x + xy.y * xy.y;
+        const float pxx = u.x * u.x + u.y * u.y, pyy = w.x * w.x + w.y * w.y;
+        coh += num / (pxx * pyy + 1e-8f);
+      }
+    }
+    coh = wave_sum(coh) / (float)(T / 2 + 1);
+    if (lane == 0 && i0 + ii < C && j0 + jj < C) {
+      float* o = conn + (((size_t)b * bt.nbands + band) * 7) * C * C + (size_t)(i0 + ii) * C + (j0 + jj);
+      const size_t fs_ = (size_t)C * C;
+      o[0 * fs_] = sqrtf(v[0] * v[0] + v[1] * v[1]) * invT;
+      o[1 * fs_] = fabsf(v[2] * invT);
+      o[2 * fs_] = fabsf(v[3] / (v[4] + 1e-8f));
+      o[3 * fs_] = coh;
+      o[4 * fs_] = v[6] * invT;
+      o[5 * fs_] = v[5] * invT;
+      o[6 * fs_] = v[7] * invT;
+    }
+  }
+}
+
+// scalar variant (4 bands): block per (window pair b, band) -> 7 global features over (C, T)  (D:436-458)
+__global__ __launch_bounds__(256) void ibs_scalar_kernel(const float* __restrict__ xb, const float* __restrict__ phase,
+                                                         const cf* __restrict__ spec, float* __restrict__ feats, int B,
+                                                         int C, int T, float fs, int nbin, BandTable bt, int band0, int ld) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* e1 = (float*)smem;  // [T] channel-averaged band signal, player 1
+  float* e2 = e1 + T;
+  __shared__ float red[8];
+  const int b = blockIdx.x, bi = blockIdx.y, band = band0 + bi;
+  const int nsig = 2 * B * C;
+  const float* X1 = xb + ((size_t)band * nsig + (size_t)b * C) * T;
+  const float* X2 = xb + ((size_t)band * nsig + (size_t)(b + B) * C) * T;
+  const float* P1 = phase + ((size_t)band * nsig + (size_t)b * C) * T;
+  const float* P2 = phase + ((size_t)band * nsig + (size_t)(b + B) * C) * T;
+  float cs_ = 0.f, sn_ = 0.f, sg_ = 0.f, sw_ = 0.f, w_ = 0.f, d_ = 0.f, q1 = 0.f, q11 = 0.f, q2 = 0.f, q22 = 0.f, q12 = 0.f;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float u = X1[(size_t)c * T + t], v = X2[(size_t)c * T + t];
+      const float d = P1[(size_t)c * T + t] - P2[(size_t)c * T + t];
+      float sn, cs;
+      sincosf(d, &sn, &cs);
+      const float sg = sgn(d), pu = u * u, pv = v * v, w = (pu + pv) * 0.5f;
+      cs_ += cs; sn_ += sn; sg_ += sg; sw_ += sg * w; w_ += w; d_ += d;
+      q1 += pu; q11 += pu * pu; q2 += pv; q22 += pv * pv; q12 += pu * pv;
+      a1 += u; a2 += v;
+    }
+    e1[t] = a1 / (float)C;
+    e2[t] = a2 / (float)C;
+  }
+  const float n = (float)C * (float)T;
+  const float Scs = block_sum(cs_, red), Ssn = block_sum(sn_, red), Ssg = block_sum(sg_, red), Ssw = block_sum(sw_, red);
+  const float Sw = block_sum(w_, red), Sd = block_sum(d_, red);
+  const float Q1 = block_sum(q1, red), Q11 = block_sum(q11, red), Q2 = block_sum(q2, red), Q22 = block_sum(q22, red);
+  const float Q12 = block_sum(q12, red);
+  // time correlation of the channel averages
+  float s1 = 0.f, s11 = 0.f, s2 = 0.f, s22 = 0.f, s12 = 0.f;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    const float u = e1[t], v = e2[t];
+    s1 += u; s11 += u * u; s2 += v; s22 += v * v; s12 += u * v;
+  }
+  const float S1 = block_sum(s1, red), S11 = block_sum(s11, red), S2 = block_sum(s2, red), S22 = block_sum(s22, red);
+  const float S12 = block_sum(s12, red);
+  // coherence with channel-averaged cross / auto spectra (D:378-392)
+  float coh = 0.f;
+  const float df = fs / (float)T;
+  for (int k = threadIdx.x; k < nbin; k += blockDim.x) {
+    const float f = (float)k * df;
+    if (f >= bt.lo[band] && f <= bt.hi[band]) {
+      cf pxy = make_float2(0.f, 0.f);
+      float pxx = 0.f, pyy = 0.f;
+      for (int c = 0; c < C; ++c) {
+        const cf u = spec[((size_t)b * C + c) * nbin + k], v = spec[((size_t)(b + B) * C + c) * nbin + k];
+        const cf xy = cmul(u, make_float2(v.x, -v.y));
+        pxy.x += xy.x; pxy.y += xy.y;
+        pxx += u.x * u.x + u.y * u.y;
+        pyy += v.x * v.x + v.y * v.y;
+      }
+      pxy.x /= C; pxy.y /= C; pxx /= C; pyy /= C;
+      coh += (pxy.x * pxy.x + pxy.y * pxy.y) / (pxx * pyy + 1e-8f);
+    }
+  }
+  const float Coh = block_sum(coh, red) / (float)(T / 2 + 1);
+  if (threadIdx.x == 0) {
+    float* o = feats + (size_t)b * ld + bi * 7;
+    o[0] = sqrtf(Scs * Scs + Ssn * Ssn) / n;
+    o[1] = fabsf(Ssg / n);
+    o[2] = fabsf(Ssw / (Sw + 1e-8f));
+    o[3] = Coh;
+    // power correlation over the flattened (C*T) axis, unbiased std (+1e-8), mean of z1*z2
+    const float m1 = Q1 / n, m2 = Q2 / n;
+    const float sd1 = sqrtf(fmaxf((Q11 - n * m1 * m1) / (n - 1.f), 0.f)) + 1e-8f;
+    const float sd2 = sqrtf(fmaxf((Q22 - n * m2 * m2) / (n - 1.f), 0.f)) + 1e-8f;
+    o[4] = ((Q12 - n * m1 * m2) / n) / (sd1 * sd2);
+    o[5] = fabsf(Sd / n);
+    const float tn = (float)T, mu1 = S1 / tn, mu2 = S2 / tn;
+    const float t1 = sqrtf(fmaxf((S11 - tn * mu1 * mu1) / (tn - 1.f), 0.f)) + 1e-8f;
+    const float t2 = sqrtf(fmaxf((S22 - tn * mu2 * mu2) / (tn - 1.f), 0.f)) + 1e-8f;
+    o[6] = ((S12 - tn * mu1 * mu2) / tn) / (t1 * t2);
+  }
+}
+
+// STFT log-magnitude: x [nsig, T] -> img [nsig, F, nfr] fp32; one block = 4 frames x 64 bins (n_fft = 128)
+__global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restrict__ x, const float* __restrict__ window,
+                                                          float* __restrict__ img, int T, int n_fft, int hop, int F,
+                                                          int nfr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* fr = (float*)smem;          // [4][n_fft] windowed frames
+  float* ct = fr + 4 * n_fft;        // [n_fft] cos table
+  float* stb = ct + n_fft;           // [n_fft] sin table
+  const int sig = blockIdx.y, f0 = blockIdx.x * 4;
+  for (int i = threadIdx.x; i < n_fft; i += blockDim.x) {
+    float sn, cs;
+    sincospif(2.0f * (float)i / (float)n_fft, &sn, &cs);
+    ct[i] = cs; stb[i] = sn;
+  }
+  for (int i = threadIdx.x; i < 4 * n_fft; i += blockDim.x) {
+    const int f = f0 + i / n_fft, n = i % n_fft;
+    float v = 0.f;
+    if (f < nfr) {
+      int t = f * hop + n - n_fft / 2;       // center=True, reflect padding
+      if (t < 0) t = -t;
+      if (t >= T) t = 2 * (T - 1) - t;
+      v = x[(size_t)sig * T + t] * window[n];
+    }
+    fr[i] = v;
+  }
+  __syncthreads();
+  const int fl = threadIdx.x / 64, k = threadIdx.x % 64;
+  const int f = f0 + fl;
+  for (int kk = k; kk < F; kk += 64) {
+    float re = 0.f, im = 0.f;
+    for (int n = 0; n < n_fft; ++n) {
+      const int idx = (kk * n) & (n_fft - 1);
+      re = fmaf(fr[fl * n_fft + n], ct[idx], re);
+      im = fmaf(fr[fl * n_fft + n], -stb[idx], im);
+    }
+    if (f < nfr) img[((size_t)sig * F + kk) * nfr + f] = logf(sqrtf(re * re + im * im) + 1e-8f);
+  }
+}
+
+// dst[b, tok, e] = instance-norm over the token axis (biased var, eps 1e-5) * gamma[e] + beta[e]; also xhat (fp32)
+template <typename T>
+__global__ void ibs_inorm_kernel(const float* __restrict__ conn, const int* __restrict__ fidx, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, T* __restrict__ out, float* __restrict__ xhat, int B, int nb,
+                                 int nf, int E, int use_norm) {
+  const int b = blockIdx.x;
+  const int ntok = nb * nf;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float s = 0.f, s2 = 0.f;
+    for (int tkn = 0; tkn < ntok; ++tkn) {
+      const int band = tkn / nf, f = fidx[tkn % nf];
+      const float v = conn[(((size_t)b * nb + band) * 7 + f) * E + e];
+      s += v;
+      s2 += v * v;
+    }
+    const float mean = s / ntok;
+    float var = 0.f;
+    for (int tkn = 0; tkn < ntok; ++tkn) {
+      const int band = tkn / nf, f = fidx[tkn % nf];
+      const float d = conn[(((size_t)b * nb + band) * 7 + f) * E + e] - mean;
+      var += d * d;
+    }
+    const float rstd = rsqrtf(var / ntok + 1e-5f);
+    for (int tkn = 0; tkn < ntok; ++tkn) {
+      const int band = tkn / nf, f = fidx[tkn % nf];
+      const float v = conn[(((size_t)b * nb + band) * 7 + f) * E + e];
+      float o = v;
+      if (use_norm) {
+        const float xh = (v - mean) * rstd;
+        xhat[((size_t)b * ntok + tkn) * E + e] = xh;
+        o = xh * gamma[e] + beta[e];
+      }
+      Elem<T>::st(out + ((size_t)b * ntok + tkn) * E + e, o);
+    }
+  }
+}
+
+// GELU(erf) forward with dropout / backward:  h = drop(gelu(u));  du = dh * mask * gelu'(u)
+template <typename T>
+__global__ void gelu_fwd_kernel(const T* __restrict__ u, T* __restrict__ h, long long n, DropCfg dc, const eg_step_state* st) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = Elem<T>::ld(u + i);
+  float g = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+  if (dc.thresh) g = eg_dropout(g, dc, st->seed_lo, st->seed_hi, (uint32_t)i);
+  Elem<T>::st(h + i, g);
+}
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ u, const T* __restrict__ dh, T* __restrict__ du, long long n, DropCfg dc,
+                                const eg_step_state* st) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = Elem<T>::ld(u + i);
+  float g = Elem<T>::ld(dh + i);
+  if (dc.thresh) g = eg_dropout(g, dc, st->seed_lo, st->seed_hi, (uint32_t)i);
+  const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
+  Elem<T>::st(du + i, g * (cdf + v * pdf));
+}
+
+// InstanceNorm affine gradients: dgamma[e] = sum_m dy[m,e] * xhat[m,e], dbeta[e] = sum_m dy[m,e]
+template <typename T>
+__global__ __launch_bounds__(256) void affine_grad_kernel(const T* __restrict__ dy, const float* __restrict__ xhat,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int E) {
+  __shared__ float rg[4][64], rb[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float g = 0.f, b = 0.f;
+  if (col < E)
+    for (int m = rl; m < M; m += 4) {
+      const float d = Elem<T>::ld(dy + (size_t)m * E + col);
+      g = fmaf(d, xhat[(size_t)m * E + col], g);
+      b += d;
+    }
+  rg[rl][threadIdx.x & 63] = g;
+  rb[rl][threadIdx.x & 63] = b;
+  __syncthreads();
+  if (rl == 0 && col < E) {
+    const int c = threadIdx.x & 63;
+    dgamma[col] = rg[0][c] + rg[1][c] + rg[2][c] + rg[3][c];
+    dbeta[col] = rb[0][c] + rb[1][c] + rb[2][c] + rb[3][c];
+  }
+}
+
+}  // namespace
+
+static int fill_bands(BandTable& bt, const float* lo, const float* hi, int nbands) {
+  if (nbands < 1 || nbands > MAX_BANDS) return 1;
+  bt.nbands = nbands;
+  for (int i = 0; i < nbands; ++i) { bt.lo[i] = lo[i]; bt.hi[i] = hi[i]; }
+  return 0;
+}
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+extern "C" int eg_ibs_analytic(const float* x, float* xb, float* phase, float* stats, float* spec, int nsig, int T,
+                               float fs, int nbin, const float* band_lo, const float* band_hi, int nbands, void* stream) {
+  EG_CHECK(x && xb && phase && stats && spec && band_lo && band_hi, "eg_ibs_analytic: null pointer");
+  EG_CHECK(nsig > 0 && is_pow2(T) && T >= 64 && T <= 2048, "eg_ibs_analytic: T=%d must be a power of two in [64, 2048]", T);
+  EG_CHECK(nbin > 0 && nbin <= T / 2 + 1, "eg_ibs_analytic: nbin=%d", nbin);
+  BandTable bt;
+  EG_CHECK(fill_bands(bt, band_lo, band_hi, nbands) == 0, "eg_ibs_analytic: nbands=%d", nbands);
+  const int lds = (3 * T + T / 2) * (int)sizeof(float2);
+  hipLaunchKernelGGL(ibs_analytic_kernel, dim3(nsig), dim3(256), lds, (hipStream_t)stream, x, xb, phase, stats, (cf*)spec,
+                     nsig, T, fs, nbin, bt);
+  EG_LAUNCH_CHECK("ibs_analytic");
+  return 0;
+}
+
+extern "C" int eg_ibs_pairs(const float* xb, const float* phase, const float* stats, const float* spec, float* conn,
+                            int B, int C, int T, float fs, int nbin, const float* band_lo, const float* band_hi, int nbands,
+                            void* stream) {
+  EG_CHECK(xb && phase && stats && spec && conn, "eg_ibs_pairs: null pointer");
+  EG_CHECK(B > 0 && C > 0 && T > 0, "eg_ibs_pairs: bad shape");
+  BandTable bt;
+  EG_CHECK(fill_bands(bt, band_lo, band_hi, nbands) == 0, "eg_ibs_pairs: nbands=%d", nbands);
+  const int Tc = T < 1024 ? T : 1024;
+  const int lds = 4 * 8 * Tc * 4;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)ibs_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 8 * 1024 * 4);
+    attr = true;
+  }
+  const int tiles = ((C + 7) / 8) * ((C + 7) / 8);
+  hipLaunchKernelGGL(ibs_pairs_kernel, dim3(B, nbands, tiles), dim3(256), lds, (hipStream_t)stream, xb, phase, stats,
+                     (const cf*)spec, conn, B, C, T, fs, nbin, bt);
+  EG_LAUNCH_CHECK("ibs_pairs");
+  return 0;
+}
+
+extern "C" int eg_ibs_scalar(const float* xb, const float* phase, const float* spec, float* feats, int B, int C, int T,
+                             float fs, int nbin, const float* band_lo, const float* band_hi, int nbands, int band0,
+                             int nout_bands, int ld, void* stream) {
+  EG_CHECK(xb && phase && spec && feats, "eg_ibs_scalar: null pointer");
+  EG_CHECK(B > 0 && C > 0 && T > 0 && band0 >= 0 && nout_bands > 0 && band0 + nout_bands <= nbands, "eg_ibs_scalar: bad shape");
+  EG_CHECK(ld >= 7 * nout_bands, "eg_ibs_scalar: ld=%d too small", ld);
+  BandTable bt;
+  EG_CHECK(fill_bands(bt, band_lo, band_hi, nbands) == 0, "eg_ibs_scalar: nbands=%d", nbands);
+  hipLaunchKernelGGL(ibs_scalar_kernel, dim3(B, nout_bands), dim3(256), 2 * T * 4, (hipStream_t)stream, xb, phase,
+                     (const cf*)spec, feats, B, C, T, fs, nbin, bt, band0, ld);
+  EG_LAUNCH_CHECK("ibs_scalar");
+  return 0;
+}
+
+extern "C" int eg_stft_logmag(const float* x, const float* window, float* img, int nsig, int T, int n_fft, int hop, int F,
+                              void* stream) {
+  EG_CHECK(x && window && img, "eg_stft_logmag: null pointer");
+  EG_CHECK(nsig > 0 && is_pow2(n_fft) && n_fft <= 1024 && hop > 0 && F > 0 && F <= n_fft / 2 + 1 && T > n_fft / 2,
+           "eg_stft_logmag: bad shape T=%d n_fft=%d hop=%d F=%d", T, n_fft, hop, F);
+  const int nfr = 1 + T / hop;
+  hipLaunchKernelGGL(stft_logmag_kernel, dim3((nfr + 3) / 4, nsig), dim3(256), 6 * n_fft * 4, (hipStream_t)stream, x, window,
+                     img, T, n_fft, hop, F, nfr);
+  EG_LAUNCH_CHECK("stft_logmag");
+  return 0;
+}
+
+extern "C" int eg_ibs_inorm(const float* conn, const int* fidx, const float* gamma, const float* beta, void* out,
+                            float* xhat, int B, int nbands, int nfeat, int E, int use_norm, int dtype, void* stream) {
+  EG_CHECK(conn && fidx && out && B > 0 && nbands > 0 && nfeat > 0 && nfeat <= 7 && E > 0, "eg_ibs_inorm: bad arguments");
+  EG_CHECK(!use_norm || (gamma && beta && xhat), "eg_ibs_inorm: instance norm needs gamma, beta and xhat");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(ibs_inorm_kernel<bf16_t>, dim3(B), dim3(256), 0, s, conn, fidx, gamma, beta, (bf16_t*)out, xhat, B,
+                       nbands, nfeat, E, use_norm);
+  else if (dtype == EG_F32)
+    hipLaunchKernelGGL(ibs_inorm_kernel<float>, dim3(B), dim3(256), 0, s, conn, fidx, gamma, beta, (float*)out, xhat, B, nbands,
+                       nfeat, E, use_norm);
+  else
+    return eg_fail("eg_ibs_inorm: bad dtype %d", dtype);
+  EG_LAUNCH_CHECK("ibs_inorm");
+  return 0;
+}
+
+extern "C" int eg_gelu_fwd(const void* u, void* h, int64_t n, int dtype, float drop_p, uint32_t drop_site,
+                           const eg_step_state* state, void* stream) {
+  EG_CHECK(u && h && n > 0 && n < (1ll << 32), "eg_gelu_fwd: bad arguments");
+  EG_CHECK(drop_p == 0.f || state, "eg_gelu_fwd: dropout needs a step state");
+  DropCfg dc = make_drop(drop_p, drop_site);
+  dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(gelu_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)u, (bf16_t*)h, (long long)n, dc, state);
+  else if (dtype == EG_F32)
+    hipLaunchKernelGGL(gelu_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)u, (float*)h, (long long)n, dc, state);
+  else
+    return eg_fail("eg_gelu_fwd: bad dtype %d", dtype);
+  EG_LAUNCH_CHECK("gelu_fwd");
+  return 0;
+}
+
+extern "C" int eg_gelu_bwd(const void* u, const void* dh, void* du, int64_t n, int dtype, float drop_p, uint32_t drop_site,
+                           const eg_step_state* state, void* stream) {
+  EG_CHECK(u && dh && du && n > 0 && n < (1ll << 32), "eg_gelu_bwd: bad arguments");
+  EG_CHECK(drop_p == 0.f || state, "eg_gelu_bwd: dropout needs a step state");
+  DropCfg dc = make_drop(drop_p, drop_site);
+  dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)u, (const bf16_t*)dh, (bf16_t*)du,
+                       (long long)n, dc, state);
+  else if (dtype == EG_F32)
+    hipLaunchKernelGGL(gelu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)u, (const float*)dh, (float*)du,
+                       (long long)n, dc, state);
+  else
+    return eg_fail("eg_gelu_bwd: bad dtype %d", dtype);
+  EG_LAUNCH_CHECK("gelu_bwd");
+  return 0;
+}
+
+extern "C" int eg_affine_grad(const void* dy, const float* xhat, float* dgamma, float* dbeta, int M, int E, int dtype,
+                              void* stream) {
+  EG_CHECK(dy && xhat && dgamma && dbeta && M > 0 && E > 0, "eg_affine_grad: bad arguments");
+  dim3 grid((E + 63) / 64);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(affine_grad_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, xhat, dgamma, dbeta, M, E);
+  else if (dtype == EG_F32)
+    hipLaunchKernelGGL(affine_grad_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, xhat, dgamma, dbeta, M, E);
+  else
+    return eg_fail("eg_affine_grad: bad dtype %d", dtype);
+  EG_LAUNCH_CHECK("affine_grad");
+  return 0;
+}

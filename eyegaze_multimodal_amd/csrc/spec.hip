@@ -1,0 +1,264 @@
+// 2-D CNN over the STFT image (dual_eeg_transformer.py:70-77, 124-127):
+//   Conv2d(1,32,3,p1)+ReLU+MaxPool2  -> direct kernel (one workgroup per image; K = 9 is too shallow for MFMA)
+//   Conv2d(32,64,3,p1)+ReLU          -> eg_gemm_nt over segmented channel-last rows (3 segments of 4 x 32 channels)
+//   AdaptiveAvgPool2d(4,4)+flatten   -> pooling kernel that emits PyTorch's (c, py, px) flatten order
+// Layouts (per image, "padded" = one zero row on top/bottom, one zero column left, three right):
+//   p1   [Hp+2][Wp+4][32]  pooled conv-1 output, channel-last      out2 [Hp+2][Wp][64] conv-2 output (rows >= Hp unused)
+//   d2   [Hp+2][Wp+4][64]  gradient of out2 (padded)               dp1  [Hp+2][Wp][32] gradient of p1 (rows >= Hp unused)
+#include "common.h"
+
+namespace {
+
+constexpr int C1 = 32, C2 = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void spec_conv1_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, T* __restrict__ p1, int F,
+                                                             int nfr) {
+  extern __shared__ float sm[];
+  const int Hp = F / 2, Wp = nfr / 2, PW = nfr + 2;
+  float* I = sm;                       // [(F+2)][PW] zero-padded image
+  float* wl = I + (F + 2) * PW;        // [32][9]
+  float* bl = wl + C1 * 9;             // [32]
+  const int im = blockIdx.x;
+  for (int i = threadIdx.x; i < (F + 2) * PW; i += blockDim.x) {
+    const int y = i / PW - 1, x = i % PW - 1;
+    I[i] = (y >= 0 && y < F && x >= 0 && x < nfr) ? img[((size_t)im * F + y) * nfr + x] : 0.f;
+  }
+  for (int i = threadIdx.x; i < C1 * 9; i += blockDim.x) wl[i] = w[i];
+  if (threadIdx.x < C1) bl[threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const int ch = threadIdx.x & 31;
+  float wk[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) wk[i] = wl[ch * 9 + i];
+  const float bb = bl[ch];
+  T* ob = p1 + (size_t)im * (Hp + 2) * (Wp + 4) * C1;
+  for (int cell = threadIdx.x >> 5; cell < Hp * Wp; cell += 8) {
+    const int y = cell / Wp, x = cell % Wp;
+    float best = 0.f;  // ReLU floor: max(relu(a_i)) = max(0, max a_i)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float a = bb;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) a = fmaf(wk[ky * 3 + kx], I[(2 * y + dy + ky) * PW + (2 * x + dx + kx)], a);
+        best = fmaxf(best, a);
+      }
+    Elem<T>::st(ob + ((size_t)(y + 1) * (Wp + 4) + (x + 1)) * C1 + ch, best);
+  }
+}
+
+// recompute conv-1, route the pooled gradient to the arg-max (ReLU-gated) and accumulate dW [32][9] + db [32]
+template <typename T>
+__global__ __launch_bounds__(256) void spec_conv1_bwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, const T* __restrict__ dp1,
+                                                             float* __restrict__ partial, int F, int nfr) {
+  extern __shared__ float sm[];
+  const int Hp = F / 2, Wp = nfr / 2, PW = nfr + 2;
+  float* I = sm;
+  float* wl = I + (F + 2) * PW;
+  float* bl = wl + C1 * 9;
+  float* red = bl + C1;  // [8][32][10]
+  const int im = blockIdx.x;
+  for (int i = threadIdx.x; i < (F + 2) * PW; i += blockDim.x) {
+    const int y = i / PW - 1, x = i % PW - 1;
+    I[i] = (y >= 0 && y < F && x >= 0 && x < nfr) ? img[((size_t)im * F + y) * nfr + x] : 0.f;
+  }
+  for (int i = threadIdx.x; i < C1 * 9; i += blockDim.x) wl[i] = w[i];
+  if (threadIdx.x < C1) bl[threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const int ch = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  float wk[9], acc[10];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) wk[i] = wl[ch * 9 + i];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+  const float bb = bl[ch];
+  const T* gb = dp1 + (size_t)im * (Hp + 2) * Wp * C1;
+  for (int cell = grp; cell < Hp * Wp; cell += 8) {
+    const int y = cell / Wp, x = cell % Wp;
+    float best = -INFINITY;
+    int by = 0, bx = 0;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float a = bb;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) a = fmaf(wk[ky * 3 + kx], I[(2 * y + dy + ky) * PW + (2 * x + dx + kx)], a);
+        if (a > best) { best = a; by = dy; bx = dx; }
+      }
+    if (best > 0.f) {
+      const float g = Elem<T>::ld(gb + ((size_t)y * Wp + x) * C1 + ch);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = fmaf(g, I[(2 * y + by + ky) * PW + (2 * x + bx + kx)], acc[ky * 3 + kx]);
+      acc[9] += g;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 10; ++i) red[(grp * C1 + ch) * 10 + i] = acc[i];
+  __syncthreads();
+  // partial[im][0:288] = dW[ch][9], partial[im][288:320] = db[ch]
+  for (int i = threadIdx.x; i < C1 * 10; i += blockDim.x) {
+    const int c = i / 10, j = i % 10;
+    float s = 0.f;
+#pragma unroll
+    for (int g8 = 0; g8 < 8; ++g8) s += red[(g8 * C1 + c) * 10 + j];
+    partial[(size_t)im * 320 + (j < 9 ? c * 9 + j : 288 + c)] = s;
+  }
+}
+
+// out2 [Hp+2][Wp][64] (post-ReLU) -> pooled [1024] = (c, py, px), mean over (Hp/4) x (Wp/4) windows
+template <typename T>
+__global__ void spec_avgpool_fwd_kernel(const T* __restrict__ out2, T* __restrict__ pooled, int Hp, int Wp) {
+  const int im = blockIdx.x, wy = Hp / 4, wx = Wp / 4;
+  const T* ib = out2 + (size_t)im * (Hp + 2) * Wp * C2;
+  for (int o = threadIdx.x; o < C2 * 16; o += blockDim.x) {
+    // consecutive threads take consecutive channels (coalesced reads); the store is strided but tiny
+    const int c = o & 63, cell = o >> 6, py = cell >> 2, px = cell & 3;
+    float s = 0.f;
+    for (int y = py * wy; y < (py + 1) * wy; ++y)
+      for (int x = px * wx; x < (px + 1) * wx; ++x) s += Elem<T>::ld(ib + ((size_t)y * Wp + x) * C2 + c);
+    Elem<T>::st(pooled + (size_t)im * (C2 * 16) + c * 16 + py * 4 + px, s / (float)(wy * wx));
+  }
+}
+
+// d2 [Hp+2][Wp+4][64] interior = dpooled / (wy*wx) where out2 > 0
+template <typename T>
+__global__ void spec_avgpool_bwd_kernel(const T* __restrict__ out2, const T* __restrict__ dpooled, T* __restrict__ d2, int Hp,
+                                        int Wp) {
+  const int im = blockIdx.x, wy = Hp / 4, wx = Wp / 4;
+  const T* ob = out2 + (size_t)im * (Hp + 2) * Wp * C2;
+  T* db = d2 + (size_t)im * (Hp + 2) * (Wp + 4) * C2;
+  const float inv = 1.0f / (float)(wy * wx);
+  for (int i = threadIdx.x; i < Hp * Wp * C2; i += blockDim.x) {
+    const int c = i & 63, x = (i >> 6) % Wp, y = (i >> 6) / Wp;
+    const float g = Elem<T>::ld(dpooled + (size_t)im * (C2 * 16) + c * 16 + (y / wy) * 4 + (x / wx));
+    const float a = Elem<T>::ld(ob + ((size_t)y * Wp + x) * C2 + c);
+    Elem<T>::st(db + ((size_t)(y + 1) * (Wp + 4) + (x + 1)) * C2 + c, a > 0.f ? g * inv : 0.f);
+  }
+}
+
+// forward layout: dst[n][(ky*4 + kx)*Cin + c] = w[n][c][ky][kx] (kx = 3 -> 0)
+// transposed (backward-data) layout: dst[c][(ky*4 + kx)*N + n] = w[n][c][2-ky][2-kx] (kx = 3 -> 0)
+template <typename T>
+__global__ void pack_conv2d_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int N, int Cin, int transposed) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)N * Cin * 12;
+  if (i >= total) return;
+  float v = 0.f;
+  if (!transposed) {
+    const int n = (int)(i / (12 * Cin)), r = (int)(i % (12 * Cin)), kk = r / Cin, c = r % Cin, ky = kk / 4, kx = kk % 4;
+    if (kx < 3) v = w[(((size_t)n * Cin + c) * 3 + ky) * 3 + kx];
+  } else {
+    const int c = (int)(i / (12 * N)), r = (int)(i % (12 * N)), kk = r / N, n = r % N, ky = kk / 4, kx = kk % 4;
+    if (kx < 3) v = w[(((size_t)n * Cin + c) * 3 + (2 - ky)) * 3 + (2 - kx)];
+  }
+  Elem<T>::st(dst + i, v);
+}
+
+// dW[n][c][ky][kx] = sum_s partial[s][n][(ky*4 + kx)*Cin + c]
+__global__ void unpack_conv2d_wgrad_kernel(const float* __restrict__ partial, float* __restrict__ dW, int splits, int N,
+                                           int Cin) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)N * Cin * 9) return;
+  const int kx = (int)(i % 3), ky = (int)((i / 3) % 3), c = (int)((i / 9) % Cin), n = (int)(i / (9 * Cin));
+  const int K = 12 * Cin;
+  float s = 0.f;
+  for (int sp = 0; sp < splits; ++sp) s += partial[((size_t)sp * N + n) * K + (ky * 4 + kx) * Cin + c];
+  dW[i] = s;
+}
+
+}  // namespace
+
+#define SPEC_DISPATCH(dtype, BF, F32, who)        \
+  if ((dtype) == EG_BF16) { BF; }                  \
+  else if ((dtype) == EG_F32) { F32; }             \
+  else return eg_fail("%s: bad dtype %d", who, (int)(dtype));
+
+static int spec_shape_ok(const char* who, int nimg, int F, int nfr) {
+  EG_CHECK(nimg > 0 && F >= 8 && F % 8 == 0 && nfr >= 8 && (nfr / 2) % 4 == 0,
+           "%s: image %dx%d unsupported (F %% 8 == 0 and floor(frames/2) %% 4 == 0 required)", who, F, nfr);
+  return 0;
+}
+
+extern "C" int eg_spec_conv1_fwd(const float* img, const float* w, const float* bias, void* p1, int nimg, int F, int nfr,
+                                 int dtype, void* stream) {
+  EG_CHECK(img && w && bias && p1, "eg_spec_conv1_fwd: null pointer");
+  if (spec_shape_ok("eg_spec_conv1_fwd", nimg, F, nfr)) return 1;
+  const int lds = ((F + 2) * (nfr + 2) + C1 * 10) * 4;
+  hipStream_t s = (hipStream_t)stream;
+  SPEC_DISPATCH(dtype,
+                hipLaunchKernelGGL(spec_conv1_fwd_kernel<bf16_t>, dim3(nimg), dim3(256), lds, s, img, w, bias, (bf16_t*)p1, F, nfr),
+                hipLaunchKernelGGL(spec_conv1_fwd_kernel<float>, dim3(nimg), dim3(256), lds, s, img, w, bias, (float*)p1, F, nfr),
+                "eg_spec_conv1_fwd");
+  EG_LAUNCH_CHECK("spec_conv1_fwd");
+  return 0;
+}
+
+extern "C" int eg_spec_conv1_bwd(const float* img, const float* w, const float* bias, const void* dp1, float* partial,
+                                 int nimg, int F, int nfr, int dtype, void* stream) {
+  EG_CHECK(img && w && bias && dp1 && partial, "eg_spec_conv1_bwd: null pointer");
+  if (spec_shape_ok("eg_spec_conv1_bwd", nimg, F, nfr)) return 1;
+  const int lds = ((F + 2) * (nfr + 2) + C1 * 10 + 8 * C1 * 10) * 4;
+  hipStream_t s = (hipStream_t)stream;
+  SPEC_DISPATCH(dtype,
+                hipLaunchKernelGGL(spec_conv1_bwd_kernel<bf16_t>, dim3(nimg), dim3(256), lds, s, img, w, bias, (const bf16_t*)dp1, partial, F, nfr),
+                hipLaunchKernelGGL(spec_conv1_bwd_kernel<float>, dim3(nimg), dim3(256), lds, s, img, w, bias, (const float*)dp1, partial, F, nfr),
+                "eg_spec_conv1_bwd");
+  EG_LAUNCH_CHECK("spec_conv1_bwd");
+  return 0;
+}
+
+extern "C" int eg_spec_avgpool_fwd(const void* out2, void* pooled, int nimg, int Hp, int Wp, int dtype, void* stream) {
+  EG_CHECK(out2 && pooled && nimg > 0 && Hp % 4 == 0 && Wp % 4 == 0, "eg_spec_avgpool_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  SPEC_DISPATCH(dtype,
+                hipLaunchKernelGGL(spec_avgpool_fwd_kernel<bf16_t>, dim3(nimg), dim3(256), 0, s, (const bf16_t*)out2, (bf16_t*)pooled, Hp, Wp),
+                hipLaunchKernelGGL(spec_avgpool_fwd_kernel<float>, dim3(nimg), dim3(256), 0, s, (const float*)out2, (float*)pooled, Hp, Wp),
+                "eg_spec_avgpool_fwd");
+  EG_LAUNCH_CHECK("spec_avgpool_fwd");
+  return 0;
+}
+
+extern "C" int eg_spec_avgpool_bwd(const void* out2, const void* dpooled, void* d2, int nimg, int Hp, int Wp, int dtype,
+                                   void* stream) {
+  EG_CHECK(out2 && dpooled && d2 && nimg > 0 && Hp % 4 == 0 && Wp % 4 == 0, "eg_spec_avgpool_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  SPEC_DISPATCH(dtype,
+                hipLaunchKernelGGL(spec_avgpool_bwd_kernel<bf16_t>, dim3(nimg), dim3(256), 0, s, (const bf16_t*)out2, (const bf16_t*)dpooled, (bf16_t*)d2, Hp, Wp),
+                hipLaunchKernelGGL(spec_avgpool_bwd_kernel<float>, dim3(nimg), dim3(256), 0, s, (const float*)out2, (const float*)dpooled, (float*)d2, Hp, Wp),
+                "eg_spec_avgpool_bwd");
+  EG_LAUNCH_CHECK("spec_avgpool_bwd");
+  return 0;
+}
+
+extern "C" int eg_pack_conv2d_weight(const float* w, void* dst, int N, int Cin, int transposed, int dtype, void* stream) {
+  EG_CHECK(w && dst && N > 0 && Cin > 0, "eg_pack_conv2d_weight: bad arguments");
+  const long long n = (long long)N * Cin * 12;
+  dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+  SPEC_DISPATCH(dtype,
+                hipLaunchKernelGGL(pack_conv2d_weight_kernel<bf16_t>, grid, dim3(256), 0, s, w, (bf16_t*)dst, N, Cin, transposed),
+                hipLaunchKernelGGL(pack_conv2d_weight_kernel<float>, grid, dim3(256), 0, s, w, (float*)dst, N, Cin, transposed),
+                "eg_pack_conv2d_weight");
+  EG_LAUNCH_CHECK("pack_conv2d_weight");
+  return 0;
+}
+
+extern "C" int eg_unpack_conv2d_wgrad(const float* partial, float* dW, int splits, int N, int Cin, void* stream) {
+  EG_CHECK(partial && dW && splits > 0 && N > 0 && Cin > 0, "eg_unpack_conv2d_wgrad: bad arguments");
+  const long long n = (long long)N * Cin * 9;
+  hipLaunchKernelGGL(unpack_conv2d_wgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial,
+                     dW, splits, N, Cin);
+  EG_LAUNCH_CHECK("unpack_conv2d_wgrad");
+  return 0;
+}

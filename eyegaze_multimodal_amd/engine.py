@@ -264,16 +264,18 @@ class Engine:
     # thin wrappers
     # ------------------------------------------------------------------------------------------
     def gemm(self, A, W, Cout, M, N, K, *, a=None, c=None, r=None, p=None, ldw=None, bias=0, residual=0, gate=0,
-             out_pre=0, act=0, drop1=(0.0, 0), drop2=(0.0, 0), gate_scale=1.0, tag=None):
+             out_pre=0, act=0, drop1=(0.0, 0), drop2=(0.0, 0), gate_scale=1.0, tag=None, seg=(0, 0)):
         probe = self.probes.get(tag) if tag else None
         if probe:
             probe[0].record(torch.cuda.current_stream(self.device))
-        self._gemm(A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale)
+        self._gemm(A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale, seg)
         if probe:
             probe[1].record(torch.cuda.current_stream(self.device))
 
-    def _gemm(self, A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale):
+    def _gemm(self, A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale,
+              seg=(0, 0)):
         dsc = GemmDesc()
+        dsc.a_seg_len, dsc.a_seg_stride = seg
         dsc.A, dsc.W, dsc.C = A, W, Cout
         dsc.bias, dsc.residual, dsc.gate, dsc.out_pre = bias or None, residual or None, gate or None, out_pre or None
         dsc.state = self.st_ptr
@@ -288,7 +290,8 @@ class Engine:
         dsc.gate_scale = gate_scale
         call("eg_gemm_nt", C.byref(dsc), self.stream)
 
-    def wgrad(self, dY, X, out_w, M, N, K, *, y=None, x=None, out_b=0, conv=None, split_out=None):
+    def wgrad(self, dY, X, out_w, M, N, K, *, y=None, x=None, out_b=0, conv=None, split_out=None, x_tile_stride=0,
+              conv2d=None):
         """dW = dY^T X (+ db = colsum dY).  split_out: list of (grad_ptr, row0, rows) for fused weights."""
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
         splits = max(1, min((M + 127) // 128, (512 + tiles - 1) // tiles, self.tn_cap // (N * K)))
@@ -297,9 +300,12 @@ class Engine:
         dsc.y = y or rowmap(N)
         dsc.x = x or rowmap(K)
         dsc.M, dsc.N, dsc.K, dsc.splits, dsc.dtype = M, N, K, splits, self.dtype
+        dsc.x_tile_stride = x_tile_stride
         call("eg_gemm_tn", C.byref(dsc), self.stream)
         pp = ptr(self.g["partial"])
-        if conv is not None:
+        if conv2d is not None:
+            call("eg_unpack_conv2d_wgrad", pp, out_w, splits, conv2d[0], conv2d[1], self.stream)
+        elif conv is not None:
             cin, kk, cp = conv
             call("eg_unpack_conv_wgrad", pp, out_w, splits, N, cin, kk, cp, K, self.stream)
         elif split_out is not None:

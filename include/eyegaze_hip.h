@@ -108,6 +108,8 @@ typedef struct eg_gemm_desc {
   float drop1_p, drop2_p;
   uint32_t drop1_site, drop2_site;
   float gate_scale; /* 1/(1-p) of the dropout that followed the gated ReLU in the forward pass, else 1 */
+  int32_t a_seg_len;    /* 0, or: an A row is K/a_seg_len segments of a_seg_len contiguous elements ... */
+  int64_t a_seg_stride; /* ... a_seg_stride elements apart (rows of a 2-D convolution window, D:74) */
 } eg_gemm_desc;
 int eg_gemm_nt(const eg_gemm_desc* d, void* stream);
 
@@ -125,6 +127,7 @@ typedef struct eg_gemm_tn_desc {
   eg_rowmap y, x;
   int32_t M, N, K, splits;
   int32_t dtype;
+  int64_t x_tile_stride; /* 0/128 = contiguous X rows; else elements between consecutive 128-column tiles */
 } eg_gemm_tn_desc;
 int eg_gemm_tn(const eg_gemm_tn_desc* d, void* stream);
 /* out[i] = (accumulate ? out[i] : 0) + sum_s partial[s*split_stride + i]; used for dW, db, LayerNorm dgamma/dbeta */
@@ -198,6 +201,55 @@ int eg_clip_coef(const float* partial, int nblk, float max_norm, eg_step_state* 
 int eg_adamw(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
              float weight_decay, const eg_step_state* state, void* stream);
 int eg_fill_f32(float* p, int64_t n, float value, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Inter-stream synchrony ("IBS") features — D:473-819 (connectivity matrices), D:178-470 (scalar variant)
+ *   eg_ibs_analytic: per signal x[T] (one window channel): rFFT, then for every band the FFT-mask band-pass
+ *       (D:527-560) and FFT Hilbert transform (D:562-591) -> xb, phase [nbands, nsig, T]; stats [nbands, nsig, 4] =
+ *       (mean, 1/(std_unbiased+1e-8)) of xb and of xb^2 (D:707-708, 751-752); spec [nsig, nbin] complex bins
+ *   eg_ibs_pairs:  conn [B, nbands, 7, C, C] = [PLV, PLI, wPLI, Coherence, Power_Corr, Phase_Diff, Time_Corr]
+ *       (D:593-758) for signals ordered [player1 windows | player2 windows] x C channels
+ *   eg_ibs_scalar: feats [B, 7*nout_bands] global features of bands band0.. (D:436-461)
+ *   eg_ibs_inorm:  token rows [B, nbands*nfeat, C*C] with InstanceNorm1d over the token axis (D:897-901)
+ *   eg_gelu_fwd/bwd: GELU(erf)+dropout of the tokenizer bottleneck (D:865-866)
+ * eg_stft_logmag — D:98-118: reflect-padded, hann-windowed n_fft-point DFT magnitudes, first F bins, log(.+1e-8)
+ *   x [nsig, T] -> img [nsig, F, 1 + T/hop] fp32
+ * ------------------------------------------------------------------------------------------- */
+int eg_ibs_analytic(const float* x, float* xb, float* phase, float* stats, float* spec, int nsig, int T, float fs,
+                    int nbin, const float* band_lo, const float* band_hi, int nbands, void* stream);
+int eg_ibs_pairs(const float* xb, const float* phase, const float* stats, const float* spec, float* conn, int B, int C,
+                 int T, float fs, int nbin, const float* band_lo, const float* band_hi, int nbands, void* stream);
+int eg_ibs_scalar(const float* xb, const float* phase, const float* spec, float* feats, int B, int C, int T, float fs,
+                  int nbin, const float* band_lo, const float* band_hi, int nbands, int band0, int nout_bands, int ld,
+                  void* stream);
+int eg_ibs_inorm(const float* conn, const int* fidx, const float* gamma, const float* beta, void* out, float* xhat, int B,
+                 int nbands, int nfeat, int E, int use_norm, int dtype, void* stream);
+/* InstanceNorm affine gradients: dgamma[e] = sum_m dy[m,e]*xhat[m,e], dbeta[e] = sum_m dy[m,e] */
+int eg_affine_grad(const void* dy, const float* xhat, float* dgamma, float* dbeta, int M, int E, int dtype, void* stream);
+int eg_gelu_fwd(const void* u, void* h, int64_t n, int dtype, float drop_p, uint32_t drop_site, const eg_step_state* state,
+                void* stream);
+int eg_gelu_bwd(const void* u, const void* dh, void* du, int64_t n, int dtype, float drop_p, uint32_t drop_site,
+                const eg_step_state* state, void* stream);
+int eg_stft_logmag(const float* x, const float* window, float* img, int nsig, int T, int n_fft, int hop, int F,
+                   void* stream);
+/* band_lo / band_hi above are HOST arrays of nbands floats (<= 8 bands); every other pointer is a device pointer. */
+
+/* ---------------------------------------------------------------------------------------------
+ * 2-D CNN over the STFT image — D:70-77, 124-127.  Conv2d(1,32,3,p1)+ReLU+MaxPool2 is a direct kernel
+ * (K = 9 is too shallow for MFMA); Conv2d(32,64,3,p1)+ReLU runs through eg_gemm_nt on segmented channel-last rows
+ * (a_seg_len = 4*32); AdaptiveAvgPool2d(4,4) emits PyTorch's (c, py, px) flatten order.
+ *   p1 [nimg, Hp+2, Wp+4, 32] zero-padded, out2 [nimg, Hp+2, Wp, 64], d2 [nimg, Hp+2, Wp+4, 64], dp1 [nimg, Hp+2, Wp, 32]
+ *   eg_spec_conv1_bwd writes partial [nimg, 320] = (dW[32][9] | db[32]) for eg_reduce_partials
+ *   eg_pack_conv2d_weight: dst[n][(ky*4+kx)*Cin + c] = w[n][c][ky][kx]; transposed: dst[c][(ky*4+kx)*N + n] = w[n][c][2-ky][2-kx]
+ * ------------------------------------------------------------------------------------------- */
+int eg_spec_conv1_fwd(const float* img, const float* w, const float* bias, void* p1, int nimg, int F, int nfr, int dtype,
+                      void* stream);
+int eg_spec_conv1_bwd(const float* img, const float* w, const float* bias, const void* dp1, float* partial, int nimg,
+                      int F, int nfr, int dtype, void* stream);
+int eg_spec_avgpool_fwd(const void* out2, void* pooled, int nimg, int Hp, int Wp, int dtype, void* stream);
+int eg_spec_avgpool_bwd(const void* out2, const void* dpooled, void* d2, int nimg, int Hp, int Wp, int dtype, void* stream);
+int eg_pack_conv2d_weight(const float* w, void* dst, int N, int Cin, int transposed, int dtype, void* stream);
+int eg_unpack_conv2d_wgrad(const float* partial, float* dW, int splits, int N, int Cin, void* stream);
 
 #ifdef __cplusplus
 }

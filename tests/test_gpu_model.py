@@ -19,6 +19,35 @@ from tests.helpers import load_golden, t  # noqa: E402
 
 DEV = "cuda"
 BASE_CONFIGS = ["cfg1_a1_2class", "cfg2_concat", "cfg3_xattn", "tiny_a1"]
+TOKEN_CONFIGS = ["cfg5_a2_spec", "a3_ibs_scalar", "a5_full", "b1_no_inorm", "b2_phase", "b3_amplitude", "tiny_full"]
+ALL = BASE_CONFIGS + TOKEN_CONFIGS
+
+
+def _check_token_stages(z, kind, cfg, eng, tight):
+    """STFT image, connectivity matrices and token rows against the reference's stage tensors."""
+    C = cfg.in_channels
+    if cfg.use_spectrogram:
+        lm = eng.a["spimg"].cpu().numpy()[: 2 * C]
+        # compared in the magnitude domain: log() of a near-zero bin amplifies fp32 noise of the 128-point DFT
+        np.testing.assert_allclose(np.exp(lm), np.exp(z[f"{kind}/stage/logmag1"]), atol=2e-5, rtol=2e-4)
+        spec = eng.a["x0"].float().cpu().view(eng.NB, eng.S, -1)[:2, 1 + eng.n_ibs: 1 + eng.n_ibs + C]
+        pos = eng.fp.flat[eng.fp.offsets["pos_embed.pos_embed.weight"]:].view(-1)[: eng.S * cfg.d_model].view(eng.S, -1).cpu()
+        got = spec - pos[1 + eng.n_ibs: 1 + eng.n_ibs + C]
+        assert relerr(got, z[f"{kind}/stage/spec1"]) < (2e-3 if tight else 3e-2)
+    if cfg.use_ibs and cfg.use_robust_ibs:
+        conn = eng.a["ib_conn"].cpu().numpy()[:2][:, :, cfg.feature_indices]
+        ref = z[f"{kind}/stage/connectivity"]
+        T = 1024
+        for j, f in enumerate(cfg.feature_indices):
+            dlt = np.abs(conn[:, :, j] - ref[:, :, j])
+            if f in (1, 2):   # sign()-based: one flipped sample of T moves PLI by 2/T
+                assert (dlt > 1e-4).mean() < 5e-3 and dlt.max() < 6.5 / T, (f, dlt.max())
+            else:
+                assert dlt.max() < 1e-4, (f, dlt.max())
+        tok = eng.a["x0"].float().cpu().view(eng.NB, eng.S, -1)[:2, 1: 1 + eng.n_ibs]
+        pos = eng.fp.flat[eng.fp.offsets["pos_embed.pos_embed.weight"]:].view(-1)[: eng.S * cfg.d_model].view(eng.S, -1).cpu()
+        got = tok - pos[1: 1 + eng.n_ibs]
+        assert relerr(got, z[f"{kind}/stage/ibs_tokens"]) < (2e-2 if tight else 4e-2)
 
 
 def build(name, dtype="bf16"):
@@ -34,7 +63,7 @@ def relerr(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
-@pytest.mark.parametrize("name", BASE_CONFIGS)
+@pytest.mark.parametrize("name", ALL)
 @pytest.mark.parametrize("kind", ["randn", "gen_eeg"])
 def test_eval_forward_matches_reference(name, kind):
     z, kw, cfg, sd, model = build(name)
@@ -52,9 +81,14 @@ def test_eval_forward_matches_reference(name, kind):
     decided = (top2[:, -1] - top2[:, -2]) > 6e-2
     assert (got.argmax(-1)[decided] == z[f"{kind}/out/argmax"][decided]).all()
     assert abs(float(out["loss_ce"]) - float(z[f"{kind}/out/loss_ce"])) < 2e-2
-    for k in ("cls1", "cls2"):
-        assert relerr(out[k].cpu(), z[f"{kind}/out/{k}"]) < 3e-2, k
+    for k in ("cls1", "cls2", "ibs_token"):
+        if k in out:
+            assert relerr(out[k].cpu(), z[f"{kind}/out/{k}"]) < 3e-2, k
+    if "ibs_logits" in out:
+        assert np.abs(out["ibs_logits"].cpu().numpy() - z[f"{kind}/out/ibs_logits"]).max() < 3e-2
+        assert abs(float(out["loss_ibs_cls"]) - float(z[f"{kind}/out/loss_ibs_cls"])) < 2e-2
     eng = next(iter(model._engines.values()))
+    _check_token_stages(z, kind, cfg, eng, tight=False)
     NB, S, d = eng.NB, eng.S, cfg.d_model
     h1 = eng.a["h1"].float().cpu().view(NB, eng.T2, d)[:2]
     assert relerr(h1, z[f"{kind}/stage/h1"]) < 2e-2
@@ -65,29 +99,36 @@ def test_eval_forward_matches_reference(name, kind):
         assert relerr(zc, z[f"{kind}/stage/zc1"]) < 3e-2
 
 
-@pytest.mark.parametrize("name", BASE_CONFIGS)
+@pytest.mark.parametrize("name", ALL)
 @pytest.mark.parametrize("kind", ["randn", "gen_eeg"])
 def test_f32_forward_and_gradients_are_tight(name, kind):
     """compute_dtype='f32' (exact-fp32 MFMA + fmaf attention): logits within 1e-4 of the reference's fp32 CPU
-    result, argmax bit-exact on every sample, every parameter gradient within 1e-3 relative (Frobenius)."""
+    result, argmax bit-exact on every sample, every parameter gradient within 1e-3 relative (Frobenius).
+    Configurations with synchrony tokens get 2e-3 / 2e-2: the sign()-based PLI / wPLI features are discontinuous
+    (one flipped sample of T=1024 moves an entry by 2e-3) and the radix-2 LDS FFT rounds differently from pocketfft."""
     z, kw, cfg, sd, model = build(name, "f32")
     model.eval()
     x1, x2, labels = t(z[f"{kind}/eeg1"]).to(DEV), t(z[f"{kind}/eeg2"]).to(DEV), t(z["labels"]).to(DEV)
     out = model(x1, x2, labels)
-    out["loss_ce"].backward()
+    loss = out["loss_ce"] + (out["loss_ibs_cls"] if "loss_ibs_cls" in out else 0.0)
+    loss.backward()
     torch.cuda.synchronize()
+    ibs = cfg.use_ibs
+    ltol, gtol = (2e-3, 2e-2) if ibs else ((3e-4, 2e-3) if cfg.use_spectrogram else (1e-4, 1e-3))
     got = out["logits"].detach().cpu().numpy()
-    assert np.abs(got - z[f"{kind}/out/logits"]).max() <= 1e-4
+    assert np.abs(got - z[f"{kind}/out/logits"]).max() <= ltol
     assert (got.argmax(-1) == z[f"{kind}/out/argmax"]).all()
-    assert abs(float(out["loss_ce"]) - float(z[f"{kind}/out/loss_ce"])) < 2e-5
+    assert abs(float(out["loss_ce"]) - float(z[f"{kind}/out/loss_ce"])) < ltol
+    eng = next(iter(model._engines.values()))
+    _check_token_stages(z, kind, cfg, eng, tight=True)
     for k in ("cls1", "cls2"):
-        np.testing.assert_allclose(out[k].detach().cpu().numpy(), z[f"{kind}/out/{k}"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), z[f"{kind}/out/{k}"], rtol=10 * ltol, atol=ltol)
     names = [str(n) for n in z[f"{kind}/grad/names"]]
     params = dict(model.named_parameters())
     gscale = float(z[f"{kind}/grad/global_norm"])
     for n, ref in zip(names, z[f"{kind}/grad/norms"]):
         got_n = float(params[n].grad.norm())
-        assert abs(got_n - ref) <= 2e-3 * ref + 1e-6 * gscale, (n, got_n, ref)
+        assert abs(got_n - ref) <= 2 * gtol * ref + 1e-6 * gscale, (n, got_n, ref)
     for key in z.files:
         if key.startswith(f"{kind}/grad/full/"):
             n = key.split("/full/")[1]
@@ -96,7 +137,7 @@ def test_f32_forward_and_gradients_are_tight(name, kind):
             if float(ref.norm()) < 1e-5 * gscale:  # k_proj.bias: mathematically zero (soft-max shift invariance)
                 assert float(g.norm()) < 1e-5 * gscale, n
                 continue
-            assert float((g - ref).norm() / ref.norm()) < 1e-3, n
+            assert float((g - ref).norm() / ref.norm()) < gtol, n
 
 
 def _oracle_grads(cfg, sd, x1, x2, labels, round_bf16):

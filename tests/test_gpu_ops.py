@@ -297,6 +297,64 @@ def test_attention_dropout_consistency():
     torch.testing.assert_close(pd[mask], (p / 0.75)[mask], rtol=2e-2, atol=2e-3)
 
 
+def test_stft_and_ibs_connectivity_match_oracle():
+    """STFT image and the 6 x 7 x C x C synchrony matrices against the CPU oracle on fresh seeded windows."""
+    import ctypes as CT
+    from oracle import dual_eeg_oracle as O
+    B, Cc, T, fs = 3, 8, 1024, 256.0
+    g = torch.Generator().manual_seed(21)
+    base = torch.randn(B, Cc, T, generator=g)
+    t_ = torch.arange(T) / fs
+    x1 = base + torch.sin(2 * math.pi * 10 * t_) + 0.5 * torch.sin(2 * math.pi * 22 * t_ + 1.0)
+    x2 = 0.6 * base.roll(5, dims=2) + 0.4 * torch.randn(B, Cc, T, generator=g) + torch.sin(2 * math.pi * 10 * t_ + 0.7)
+    x1d, x2d = x1.contiguous().to(DEV), x2.contiguous().to(DEV)
+    # STFT
+    win = torch.hann_window(128).to(DEV)
+    img = torch.zeros(B * Cc, 64, 17, device=DEV)
+    call("eg_stft_logmag", ptr(x1d), ptr(win), ptr(img), B * Cc, T, 128, 64, 64, 0)
+    torch.cuda.synchronize()
+    # magnitude domain: log() of a near-zero bin amplifies fp32 rounding of the 128-point DFT
+    np.testing.assert_allclose(np.exp(img.cpu().numpy()), np.exp(O.stft_logmag(x1, 128, 64, 64).numpy()), atol=2e-5, rtol=2e-4)
+    # connectivity
+    bands = O.ROBUST_BANDS
+    lo = (CT.c_float * 6)(*[b[0] for b in bands])
+    hi = (CT.c_float * 6)(*[b[1] for b in bands])
+    nsig, nbin = 2 * B * Cc, 181
+    xcat = torch.cat([x1d, x2d], 0)
+    xb, ph = torch.zeros(6, nsig, T, device=DEV), torch.zeros(6, nsig, T, device=DEV)
+    stats, spec = torch.zeros(6, nsig, 4, device=DEV), torch.zeros(nsig, nbin, 2, device=DEV)
+    conn = torch.zeros(B, 6, 7, Cc, Cc, device=DEV)
+    call("eg_ibs_analytic", ptr(xcat), ptr(xb), ptr(ph), ptr(stats), ptr(spec), nsig, T, fs, nbin, CT.addressof(lo), CT.addressof(hi), 6, 0)
+    call("eg_ibs_pairs", ptr(xb), ptr(ph), ptr(stats), ptr(spec), ptr(conn), B, Cc, T, fs, nbin, CT.addressof(lo), CT.addressof(hi), 6, 0)
+    torch.cuda.synchronize()
+    cfg = O.ModelCfg(in_channels=Cc)
+    ref = O.ibs_connectivity(x1, x2, cfg).numpy()
+    got = conn.cpu().numpy()
+    # band-limited signal of the broadband band against the oracle's FFT-mask band-pass
+    np.testing.assert_allclose(xb[0, :B * Cc].cpu().numpy().reshape(B, Cc, T), O.bandpass(x1, fs, 0.5, 45).numpy(), atol=2e-5)
+    for f in range(7):
+        d = np.abs(got[:, :, f] - ref[:, :, f])
+        if f in (1, 2):
+            assert (d > 1e-4).mean() < 5e-3 and d.max() < 6.5 / T, (f, d.max())
+        else:
+            assert d.max() < 1e-4, (f, d.max())
+    # scalar variant (4 bands x 7 global features)
+    lo4 = (CT.c_float * 4)(*[b[0] for b in O.SCALAR_BANDS])
+    hi4 = (CT.c_float * 4)(*[b[1] for b in O.SCALAR_BANDS])
+    xb4, ph4 = torch.zeros(4, nsig, T, device=DEV), torch.zeros(4, nsig, T, device=DEV)
+    st4 = torch.zeros(4, nsig, 4, device=DEV)
+    call("eg_ibs_analytic", ptr(xcat), ptr(xb4), ptr(ph4), ptr(st4), ptr(spec), nsig, T, fs, nbin, CT.addressof(lo4), CT.addressof(hi4), 4, 0)
+    feats = torch.zeros(B, 64, device=DEV)
+    call("eg_ibs_scalar", ptr(xb4), ptr(ph4), ptr(spec), ptr(feats), B, Cc, T, fs, nbin, CT.addressof(lo4), CT.addressof(hi4), 4, 0, 4, 64, 0)
+    torch.cuda.synchronize()
+    refs = O.ibs_scalar_features(x1, x2, cfg).numpy()
+    gots = feats.cpu().numpy()[:, :28]
+    d = np.abs(gots - refs)
+    flip = np.isin(np.arange(28) % 7, [1, 2])
+    assert d[:, ~flip].max() < 1e-4, d[:, ~flip].max()
+    assert d[:, flip].max() < 2e-3
+
+
 def test_heads_and_ce():
     B, S, D, ncls, off = 8, 20, 64, 3, 5
     dtype = L.EG_F32
