@@ -266,6 +266,50 @@ __global__ void rows_gather_gate_kernel(const T* __restrict__ src, const T* __re
   }
 }
 
+// FuzzyGatingFusion.forward (3_Models/fusion/fuzzy_gating_fusion.py:297-390), one thread per sample, K <= 16 classes.
+// prm = [tau_img, tau_eeg, c_unrel_img, c_unrel_eeg, ls_rel_img, ls_rel_eeg, ls_unrel_img, ls_unrel_eeg, beta0..3]
+// mode: 0 full, 1 no_temperature, 2 no_fuzzification, 3 fixed_weights
+__device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float entropy_k(const float* z, int K, float eps_log) {
+  float mx = -INFINITY, se = 0.f, h = 0.f;
+  for (int c = 0; c < K; ++c) mx = fmaxf(mx, z[c]);
+  for (int c = 0; c < K; ++c) se += expf(z[c] - mx);
+  for (int c = 0; c < K; ++c) {
+    const float p = expf(z[c] - mx) / se;
+    h -= p * logf(p + eps_log);
+  }
+  return h;
+}
+__global__ void fuzzy_gate_fwd_kernel(const float* __restrict__ zi, const float* __restrict__ ze, const float* __restrict__ prm,
+                                      float* __restrict__ fused, float* __restrict__ alpha_out, int B, int K, int mode,
+                                      float eps_temp, float eps_log, float eps_div) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float a[16], e[16];
+  float ti = 1.f, te = 1.f;
+  if (mode == 0 || mode == 2) { ti = softplus_f(prm[0]) + eps_temp; te = softplus_f(prm[1]) + eps_temp; }
+  for (int c = 0; c < K; ++c) { a[c] = zi[(size_t)b * K + c] / ti; e[c] = ze[(size_t)b * K + c] / te; }
+  const float Hi = entropy_k(a, K, eps_log), He = entropy_k(e, K, eps_log);
+  float al;
+  if (mode == 3) {
+    al = 0.5f;
+  } else if (mode == 2) {
+    const float hmax = logf((float)K);
+    const float ci = fmaxf(1.0f - Hi / (hmax + eps_div), 0.f), ce = fmaxf(1.0f - He / (hmax + eps_div), 0.f);
+    al = fminf(fmaxf(ci / (ci + ce + eps_div), 0.f), 1.f);
+  } else {
+    auto mu = [&](float x, float c, float ls) { const float s = expf(ls); return expf(-((x - c) * (x - c)) / (2.f * s * s + eps_div)); };
+    const float ir = mu(Hi, 0.f, prm[4]), iu = mu(Hi, prm[2], prm[6]);
+    const float er = mu(He, 0.f, prm[5]), eu = mu(He, prm[3], prm[7]);
+    const float w[4] = {ir * eu, iu * er, ir * er, iu * eu};
+    float num = 0.f, den = 0.f;
+    for (int k = 0; k < 4; ++k) { num += w[k] / (1.f + expf(-prm[8 + k])); den += w[k]; }
+    al = fminf(fmaxf(num / (den + eps_div), 0.f), 1.f);
+  }
+  alpha_out[b] = al;
+  for (int c = 0; c < K; ++c) fused[(size_t)b * K + c] = al * a[c] + (1.f - al) * e[c];
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL_BF16, CALL_F32, who)          \
@@ -384,5 +428,15 @@ extern "C" int eg_rows_gather_gate(const void* src, const void* gate, void* dst,
              hipLaunchKernelGGL(rows_gather_gate_kernel<float>, grid, dim3(64), 0, s, (const float*)src, (const float*)gate, (float*)dst, to_rowmap(dmap), S, D, R, off, pair_shift, gate_scale),
              "eg_rows_gather_gate");
   EG_LAUNCH_CHECK("rows_gather_gate");
+  return 0;
+}
+
+extern "C" int eg_fuzzy_gate_fwd(const float* z_img, const float* z_eeg, const float* params, float* fused, float* alpha,
+                                 int B, int K, int mode, float eps_temp, float eps_log, float eps_div, void* stream) {
+  EG_CHECK(z_img && z_eeg && params && fused && alpha, "eg_fuzzy_gate_fwd: null pointer");
+  EG_CHECK(B > 0 && K > 1 && K <= 16 && mode >= 0 && mode <= 3, "eg_fuzzy_gate_fwd: bad shape / mode");
+  hipLaunchKernelGGL(fuzzy_gate_fwd_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, z_img, z_eeg, params,
+                     fused, alpha, B, K, mode, eps_temp, eps_log, eps_div);
+  EG_LAUNCH_CHECK("fuzzy_gate_fwd");
   return 0;
 }

@@ -24,10 +24,13 @@ def _sines(rng, C, T, fs, ncomp):
 def synth_windows(n: int, C: int = 8, T: int = 1024, num_classes: int = 3, fs: float = 256.0, noise_std: float = 0.1,
                   seed: int = 0):
     """Returns eeg1, eeg2 [n,C,T] f32 (z-scored per window) and labels [n] i64.
-    class c: stream 2 = coupling[c] * (stream 1 delayed by lag[c]) + (1-coupling[c]) * independent mixture."""
+    class c: stream 2 = coupling[c] * (stream 1 delayed by lag[c]) + (1-coupling[c]) * independent mixture, and both
+    streams carry a class-specific rhythm (6 / 11 / 20 / 31 / 43 Hz, random phase per window) on half of the channels."""
     rng = np.random.default_rng(seed)
     coupling = np.linspace(0.0, 0.9, num_classes)
     lags = [0, 7, 19, 3, 11][:num_classes]
+    marker = [6.0, 11.0, 20.0, 31.0, 43.0][:num_classes]
+    tt = np.arange(T, dtype=np.float32) / fs
     x1 = np.zeros((n, C, T), np.float32)
     x2 = np.zeros((n, C, T), np.float32)
     y = rng.integers(0, num_classes, size=n)
@@ -35,6 +38,9 @@ def synth_windows(n: int, C: int = 8, T: int = 1024, num_classes: int = 3, fs: f
         a = _sines(rng, C, T, fs, 3) + rng.normal(0, noise_std, (C, T)).astype(np.float32)
         b = _sines(rng, C, T, fs, 3) + rng.normal(0, noise_std, (C, T)).astype(np.float32)
         c = int(y[i])
+        m = (0.8 * np.sin(2 * np.pi * marker[c] * tt + rng.uniform(0, 2 * np.pi))).astype(np.float32)
+        a[::2] += m
+        b[1::2] += m
         x1[i] = zscore_window(a)
         x2[i] = zscore_window(coupling[c] * np.roll(a, lags[c], axis=1) + (1 - coupling[c]) * b)
     return torch.from_numpy(x1), torch.from_numpy(x2), torch.from_numpy(y.astype(np.int64))

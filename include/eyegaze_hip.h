@@ -191,6 +191,13 @@ int eg_batch_rowsum(const void* dseq, float* out, int NB, int S, int D, int rows
 int eg_rows_gather_gate(const void* src, const void* gate, void* dst, eg_rowmap dmap, int nb, int S, int D, int R,
                         int off, int pair_shift, float gate_scale, int dtype, void* stream);
 
+/* FuzzyGatingFusion.forward — 3_Models/fusion/fuzzy_gating_fusion.py:297-390 (config 5's logit-level fusion).
+ * params = [tau_img, tau_eeg, c_unreliable_img, c_unreliable_eeg, log_sigma_reliable_img, log_sigma_reliable_eeg,
+ *           log_sigma_unreliable_img, log_sigma_unreliable_eeg, beta[4]] (12 device floats);
+ * mode 0 full, 1 no_temperature, 2 no_fuzzification, 3 fixed_weights.  Forward only in this version. */
+int eg_fuzzy_gate_fwd(const float* z_img, const float* z_eeg, const float* params, float* fused, float* alpha, int B,
+                      int K, int mode, float eps_temp, float eps_log, float eps_div, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Optimiser over flat fp32 buffers — clip_grad_norm_(1.0) + AdamW (T:221-222, T:401-405)
  *   eg_grad_sqnorm: partial[blk] = sum of squares;  eg_clip_coef: state->grad_norm / clip_coef (no host sync)

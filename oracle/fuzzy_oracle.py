@@ -1,0 +1,46 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  CPU restatement of FuzzyGatingFusion.forward
+(reference 3_Models/fusion/fuzzy_gating_fusion.py:297-390; helpers :132-295), pinned by tests/golden/fuzzy_gating.npz
+(generated from the reference by oracle/make_golden.py) and by the reference's own known answers
+(:430-538: alpha = 0.5000 / 0.7907 / 0.2102, T_img = 1.5, T_eeg = 1.0)."""
+import math
+
+import numpy as np
+
+
+def softplus(x):
+    return np.log1p(np.exp(-abs(x))) + max(x, 0.0)
+
+
+def fuzzy_forward(z_img, z_eeg, p, mode="full", eps_temp=0.1, eps_log=1e-8, eps_div=1e-8):
+    """z_*: [B, K] float arrays; p: dict of the module's scalar parameters (state_dict names)."""
+    z_img, z_eeg = np.asarray(z_img, np.float32), np.asarray(z_eeg, np.float32)  # fp32 like the reference
+    K = z_img.shape[1]
+    if mode in ("no_temperature", "fixed_weights"):            # :323-327
+        zi, ze = z_img, z_eeg
+    else:                                                      # :328-332
+        zi = z_img / np.float32(softplus(float(p["tau_img"])) + eps_temp)
+        ze = z_eeg / np.float32(softplus(float(p["tau_eeg"])) + eps_temp)
+
+    def entropy(z):                                            # :132-146
+        e = np.exp(z - z.max(-1, keepdims=True))
+        pr = e / e.sum(-1, keepdims=True)
+        return -(pr * np.log(pr + np.float32(eps_log))).sum(-1)
+    Hi, He = entropy(zi), entropy(ze)
+    if mode == "fixed_weights":                                # :338-340
+        alpha = np.full(z_img.shape[0], 0.5)
+    elif mode == "no_fuzzification":                           # :264-295
+        hmax = np.float32(math.log(K))
+        ci = np.clip(np.float32(1) - Hi / (hmax + np.float32(eps_div)), 0, None)
+        ce = np.clip(np.float32(1) - He / (hmax + np.float32(eps_div)), 0, None)
+        alpha = np.clip(ci / (ci + ce + np.float32(eps_div)), 0, 1)
+    else:
+        def mu(x, c, ls):                                      # :148-168
+            s = math.exp(float(ls))
+            return np.exp(-((x - c) ** 2) / (2 * s * s + eps_div))
+        ir, iu = mu(Hi, 0.0, p["log_sigma_reliable_img"]), mu(Hi, float(p["c_unreliable_img"]), p["log_sigma_unreliable_img"])
+        er, eu = mu(He, 0.0, p["log_sigma_reliable_eeg"]), mu(He, float(p["c_unreliable_eeg"]), p["log_sigma_unreliable_eeg"])
+        w = np.stack([ir * eu, iu * er, ir * er, iu * eu], -1)  # :228-233
+        theta = 1 / (1 + np.exp(-np.asarray(p["beta"], np.float64)))
+        alpha = np.clip((w * theta).sum(-1) / (w.sum(-1) + eps_div), 0, 1)  # :256-262
+    fused = alpha[:, None] * zi + (1 - alpha[:, None]) * ze    # :386-388
+    return fused, alpha

@@ -429,3 +429,20 @@ def test_rejects_bad_arguments():
         call("eg_attention_fwd", ptr(A), ptr(A), ptr(A), 1, 200, 1, 0, L.EG_BF16, 0.0, 0, 0, 0)  # S too long
     with pytest.raises(L.EgError):
         call("eg_attention_fwd", ptr(A), ptr(A), ptr(A), 1, 8, 1, 0, 7, 0.0, 0, 0, 0)  # unknown dtype
+
+
+@pytest.mark.parametrize("mode", ["full", "no_temperature", "no_fuzzification", "fixed_weights"])
+def test_fuzzy_gating_fusion_matches_reference(mode):
+    """HIP FuzzyGatingFusion.forward against fixtures emitted by the reference (all four ablation modes)."""
+    from eyegaze_multimodal_amd.fuzzy_gating_fusion import FuzzyGatingFusion
+    from tests.helpers import GOLDEN
+    z = np.load(GOLDEN / "fuzzy_gating.npz")
+    m = FuzzyGatingFusion(num_classes=3, mode=mode)
+    sd = {k.split("/state/")[1]: torch.from_numpy(z[k]) for k in z.files if k.startswith(mode + "/state/")}
+    m.load_state_dict(sd, strict=True)
+    fused, alpha, _ = m(torch.from_numpy(z["z_img"]).to(DEV), torch.from_numpy(z["z_eeg"]).to(DEV))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(fused.cpu().numpy(), z[mode + "/z_fused"], atol=2e-5)
+    # sample 0 of no_fuzzification is 0/0 in fp32 (both entropies at their maximum): skip its alpha
+    sl = slice(1, None) if mode == "no_fuzzification" else slice(None)
+    np.testing.assert_allclose(alpha.cpu().numpy()[sl], z[mode + "/alpha"][sl], atol=2e-5)
