@@ -104,6 +104,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT<T> p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // epilogue operands (residual / gate rows of this thread's 8 output chunks) are requested NOW, so their HBM
+  // latency hides under the K loop instead of serialising the epilogue (16-bit types: 8 x 16 B each)
+  constexpr bool kPrefetchEpi = sizeof(T) == 2;
+  const int ech = tid & 15, en = n0 + ech * 8;
+  u32x4 pres[8], pgate[8];
+  if (kPrefetchEpi) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + (tid >> 4) + 16 * i;
+      const bool ok = m < p.M && en < p.N;
+      pres[i] = (u32x4){0u, 0u, 0u, 0u};
+      pgate[i] = (u32x4){0u, 0u, 0u, 0u};
+      if (ok && p.residual) pres[i] = *(const u32x4*)(p.residual + row_off(p.r, m) + en);
+      if (ok && p.gate) pgate[i] = *(const u32x4*)(p.gate + row_off(p.c, m) + en);
+    }
+  }
+
   const int nk = p.K / (128 / (int)sizeof(T));
   // A rows may consist of several equally long segments (2-D convolution windows): K-tile kt starts at koff(kt)
   auto koff = [&](int kt) -> size_t {
@@ -181,7 +198,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT<T> p) {
       const long long coff = row_off(p.c, m) + n;
       if (p.gate) {
         float gv[8];
-        load8(p.gate + coff, gv);
+        if (kPrefetchEpi) load8((const T*)&pgate[i], gv);
+        else load8(p.gate + coff, gv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = gv[j] > 0.f ? v[j] * p.gate_scale : 0.f;
       }
@@ -196,7 +214,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT<T> p) {
       if (p.out_pre) store8(p.out_pre + row_off(p.pm, m) + n, v);
       if (p.residual) {
         float rv[8];
-        load8(p.residual + row_off(p.r, m) + n, rv);
+        if (kPrefetchEpi) load8((const T*)&pres[i], rv);
+        else load8(p.residual + row_off(p.r, m) + n, rv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += rv[j];
       }
@@ -217,6 +236,9 @@ struct GemmTN {
   RowMap y, x;
   int M, N, K, splits, rows_per_split, tiles_k, tiles_nk;
   long long x_tile_stride;  // elements between consecutive 128-column tiles of an X row (128 = contiguous)
+  // output slab of one split: N/part_rows parts of [part_rows x K weights | part_rows bias sums (if has_bias)]
+  int part_rows, has_bias;
+  long long part_size, slab;
 };
 
 __device__ __forceinline__ int tn_swz(int r) { return (((r & 3) | ((r >> 1) & 4)) << 1); }
@@ -284,6 +306,30 @@ __device__ __forceinline__ void tn_mma<float>(const char* bufY, const char* bufX
   }
 }
 
+// column sums of the dY tile (rows 16*half .. +15, column `col`) straight from its swizzled LDS image
+template <typename T>
+__device__ __forceinline__ float tn_tile_colsum(const char* bufY, int col, int half);
+template <>
+__device__ __forceinline__ float tn_tile_colsum<bf16_t>(const char* bufY, int col, int half) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = half * 16 + i;
+    s += bf2f(*(const bf16_t*)(bufY + r * 256 + (((col >> 3) ^ tn_swz(r)) << 4) + (col & 7) * 2));
+  }
+  return s;
+}
+template <>
+__device__ __forceinline__ float tn_tile_colsum<float>(const char* bufY, int col, int half) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = half * 16 + i;
+    s += *(const float*)(bufY + r * 512 + (((col >> 2) ^ tn_swz(r)) << 4) + (col & 3) * 4);
+  }
+  return s;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -334,6 +380,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN<T> p) {
     }
   };
   const int nt = (mend - mbeg + 31) / 32;
+  const bool do_bias = p.has_bias && (t % p.tiles_k) == 0;  // the k-tile-0 blocks see every dY row exactly once
+  float bsum = 0.f;
   if (nt > 0) {
     load_tile(mbeg);
     store_tile(smem);
@@ -344,11 +392,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN<T> p) {
     const bool more = it + 1 < nt;
     if (more) load_tile(mbeg + (it + 1) * 32);
     tn_mma<T>(smem + cur * 2 * TILEB, smem + cur * 2 * TILEB + TILEB, wn, wk, lane, acc);
+    if (do_bias) bsum += tn_tile_colsum<T>(smem + cur * 2 * TILEB, tid & 127, tid >> 7);
     if (more) store_tile(smem + (cur ^ 1) * 2 * TILEB);
     __syncthreads();
   }
   // D[i = k][j = n]: lane holds 4 consecutive k (rows 4g+r) for column n = lane&15
-  float* out = p.partial + (size_t)split * p.N * p.K;
+  float* out = p.partial + (size_t)split * p.slab;
   const int l15 = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int ki = 0; ki < 4; ++ki)
@@ -356,8 +405,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN<T> p) {
     for (int ni = 0; ni < 4; ++ni) {
       const int n = n0 + wn * 64 + ni * 16 + l15;
       const int k = k0 + wk * 64 + ki * 16 + 4 * g;
-      if (n < p.N && k < p.K) *(f32x4*)(out + (size_t)n * p.K + k) = acc[ki][ni];
+      if (n < p.N && k < p.K) {
+        const int part = n / p.part_rows;
+        *(f32x4*)(out + (size_t)part * p.part_size + (size_t)(n - part * p.part_rows) * p.K + k) = acc[ki][ni];
+      }
     }
+  if (do_bias) {
+    float* red = (float*)smem;  // the staging buffers are free after the loop's final barrier
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < 128) {
+      const int n = n0 + tid;
+      if (n < p.N) {
+        const int part = n / p.part_rows;
+        out[(size_t)part * p.part_size + (size_t)p.part_rows * p.K + (n - part * p.part_rows)] = red[tid] + red[tid + 128];
+      }
+    }
+  }
 }
 
 // out[i] = sum_s partial[s*sstride + i].  256 threads = 8 float4 columns x 32 split lanes, so short outputs
@@ -507,6 +571,10 @@ static int launch_gemm_tn(const eg_gemm_tn_desc* d, hipStream_t s) {
   p.tiles_k = (d->K + 127) / 128;
   p.tiles_nk = p.tiles_k * ((d->N + 127) / 128);
   p.x_tile_stride = d->x_tile_stride > 0 ? d->x_tile_stride : 128;
+  p.part_rows = d->part_rows > 0 ? d->part_rows : d->N;
+  p.has_bias = d->has_bias ? 1 : 0;
+  p.part_size = (long long)p.part_rows * d->K + (p.has_bias ? p.part_rows : 0);
+  p.slab = (long long)(d->N / p.part_rows) * p.part_size;
   const int lds = 4 * 32 * TNCfg<T>::ROWB;
   hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(p.tiles_nk * d->splits), dim3(256), lds, s, p);
   EG_LAUNCH_CHECK("gemm_tn");
@@ -522,6 +590,8 @@ extern "C" int eg_gemm_tn(const eg_gemm_tn_desc* d, void* stream) {
   EG_CHECK(d->y.row_stride % al == 0 && d->y.group_stride % al == 0 && d->x.row_stride % al == 0 &&
                d->x.group_stride % al == 0, "eg_gemm_tn: rows must be 16-B aligned");
   EG_CHECK(((uintptr_t)d->dY | (uintptr_t)d->X | (uintptr_t)d->partial) % 16 == 0, "eg_gemm_tn: alignment");
+  EG_CHECK(d->part_rows == 0 || (d->N % d->part_rows == 0 && d->part_rows % 4 == 0), "eg_gemm_tn: part_rows=%d must divide N", d->part_rows);
+  EG_CHECK(!d->has_bias || d->K % 4 == 0, "eg_gemm_tn: fused bias sums need K %% 4 == 0");
   EG_CHECK(d->x_tile_stride == 0 || (d->x_tile_stride % al == 0 && d->K % 128 == 0), "eg_gemm_tn: x_tile_stride needs K %% 128 == 0");
   hipStream_t s = (hipStream_t)stream;
   return d->dtype == EG_BF16 ? launch_gemm_tn<bf16_t>(d, s) : launch_gemm_tn<float>(d, s);

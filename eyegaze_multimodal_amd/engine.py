@@ -236,8 +236,8 @@ class Engine:
         # TN split-K partials: sized for the largest product (conv-1 weights / FFN)
         self.tn_cap = 24 * 1024 * 1024  # floats (96 MB)
         g["partial"] = self._t(self.tn_cap, dtype=torch.float32)
-        g["lnpart"] = self._t(512 * 2 * max(d, 8), dtype=torch.float32)
-        g["cspart"] = self._t(256 * max(3 * d, F), dtype=torch.float32)
+        g["lnpart"] = self._t(2048 * 2 * max(d, 8), dtype=torch.float32)
+        g["cspart"] = self._t(512 * max(3 * d, F), dtype=torch.float32)
         self.g = g
 
     # ------------------------------------------------------------------------------------------
@@ -291,18 +291,39 @@ class Engine:
         call("eg_gemm_nt", C.byref(dsc), self.stream)
 
     def wgrad(self, dY, X, out_w, M, N, K, *, y=None, x=None, out_b=0, conv=None, split_out=None, x_tile_stride=0,
-              conv2d=None):
-        """dW = dY^T X (+ db = colsum dY).  split_out: list of (grad_ptr, row0, rows) for fused weights."""
+              conv2d=None, linear=None):
+        """dW = dY^T X (+ db = colsum dY).
+        linear=[prefix, ...]: the product feeds N/len(linear) rows to each `prefix.weight` / `prefix.bias`; when those
+        parameters are laid out back to back in the flat buffer (they are: registration order) the bias sums are fused
+        into the GEMM launch and ONE reduce writes every weight and bias gradient.
+        conv / conv2d: tap-major partials are un-permuted into the parameter layout; out_b via a column-sum launch."""
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        splits = max(1, min((M + 127) // 128, (512 + tiles - 1) // tiles, self.tn_cap // (N * K)))
+        fused = False
+        if linear is not None:
+            P = N // len(linear)
+            base = self.fp.offsets[linear[0] + ".weight"]
+            fused = P % 4 == 0 and all(self.fp.offsets[n + ".weight"] == base + i * (P * K + P) and
+                                       self.fp.offsets[n + ".bias"] == base + i * (P * K + P) + P * K
+                                       for i, n in enumerate(linear))
+        slab = N * K + (N if fused else 0)
+        splits = max(1, min((M + 127) // 128, (512 + tiles - 1) // tiles, self.tn_cap // slab))
         dsc = GemmTNDesc()
         dsc.dY, dsc.X, dsc.partial = dY, X, ptr(self.g["partial"])
         dsc.y = y or rowmap(N)
         dsc.x = x or rowmap(K)
         dsc.M, dsc.N, dsc.K, dsc.splits, dsc.dtype = M, N, K, splits, self.dtype
         dsc.x_tile_stride = x_tile_stride
+        if fused:
+            dsc.part_rows, dsc.has_bias = N // len(linear), 1
         call("eg_gemm_tn", C.byref(dsc), self.stream)
         pp = ptr(self.g["partial"])
+        if fused:
+            call("eg_reduce_partials", pp, self.fp.g_ptr(linear[0] + ".weight"), slab, splits, slab, 0, self.stream)
+            return
+        if linear is not None:  # non-contiguous parameters: per-parameter reduces + a column-sum launch
+            P = N // len(linear)
+            split_out = [(self.fp.g_ptr(n + ".weight"), i * P, P) for i, n in enumerate(linear)]
+            out_b = [(self.fp.g_ptr(n + ".bias"), i * P, P) for i, n in enumerate(linear)]
         if conv2d is not None:
             call("eg_unpack_conv2d_wgrad", pp, out_w, splits, conv2d[0], conv2d[1], self.stream)
         elif conv is not None:
@@ -314,7 +335,7 @@ class Engine:
         else:
             call("eg_reduce_partials", pp, out_w, N * K, splits, N * K, 0, self.stream)
         if out_b:
-            nblk = min(128, (M + 63) // 64)
+            nblk = min(512, (M + 63) // 64)
             call("eg_colsum", dY, dsc.y, M, N, ptr(self.g["cspart"]), nblk, self.dtype, self.stream)
             if isinstance(out_b, (list, tuple)):
                 for gp, col0, cols in out_b:
@@ -328,7 +349,7 @@ class Engine:
 
     def ln_bwd(self, dy, x, stats, gname, dx, dx_drop=None, d1=(0.0, 0), d2=(0.0, 0)):
         d = self.cfg.d_model
-        nblk = 512
+        nblk = max(64, min(2048, self.M // 16))
         call("eg_layernorm_bwd", ptr(dy), ptr(x), ptr(stats), self.fp.p_ptr(gname + ".weight"), ptr(dx), ptr(dx_drop),
              ptr(self.g["lnpart"]), nblk, self.M, d, self.dtype, d1[0], d1[1], d2[0], d2[1], self.st_ptr, self.stream)
         lp = ptr(self.g["lnpart"])
@@ -473,10 +494,9 @@ class Engine:
              ptr(glogits), ptr(g["dlogits"]), ptr(g["dhcl"]), fp.g_ptr("classifier.3.weight"), fp.g_ptr("classifier.3.bias"),
              B, d, cfg.num_classes, 1, sc, self.dtype, st)
         self.gemm(ptr(g["dhcl"]), ptr(w["c0T"]), ptr(g["dzf"]), B, 3 * d, d)
-        self.wgrad(ptr(g["dhcl"]), ptr(a["zf"]), fp.g_ptr("classifier.0.weight"), B, d, 3 * d, out_b=fp.g_ptr("classifier.0.bias"))
+        self.wgrad(ptr(g["dhcl"]), ptr(a["zf"]), 0, B, d, 3 * d, linear=["classifier.0"])
         self.gemm(ptr(g["dzf"]), ptr(w["sfT"]), ptr(g["dcomb"]), B, 3 * d, d, a=rowmap(3 * d))
-        self.wgrad(ptr(g["dzf"]), ptr(a["comb"]), fp.g_ptr("symmetric_fusion.proj.weight"), B, d, 3 * d, y=rowmap(3 * d),
-                   out_b=fp.g_ptr("symmetric_fusion.proj.bias"))
+        self.wgrad(ptr(g["dzf"]), ptr(a["comb"]), 0, B, d, 3 * d, y=rowmap(3 * d), linear=["symmetric_fusion.proj"])
         dibs = None
         if cfg.use_ibs:
             sc3 = 1.0 / 0.7 if train else 1.0
@@ -487,8 +507,7 @@ class Engine:
             if Kp != d // 2:
                 raise L.EgError("ibs_classifier hidden width must be a multiple of the GEMM K-tile")
             self.gemm(ptr(g["dhib"]), ptr(w["i0T"]), ptr(g["dibs_pool"]), B, d, d // 2)
-            self.wgrad(ptr(g["dhib"]), ptr(a["ibs_pool"]), fp.g_ptr("ibs_classifier.0.weight"), B, d // 2, d,
-                       out_b=fp.g_ptr("ibs_classifier.0.bias"))
+            self.wgrad(ptr(g["dhib"]), ptr(a["ibs_pool"]), 0, B, d // 2, d, linear=["ibs_classifier.0"])
             dibs = g["dibs_pool"]
         z = self.z_final
         dz = g["dzA"]
@@ -501,14 +520,11 @@ class Engine:
         def attn_block_bwd(pre, l, x_in, dr, drm, kv_shift, site_attn, dx_out):
             """dr: grad of the pre-LN sum (residual path), drm: same, masked by the branch dropout."""
             names = [pre + n for n in ("q_proj", "k_proj", "v_proj")]
-            self.wgrad(ptr(drm), ptr(a[f"ctx{l}"]), fp.g_ptr(pre + "out_proj.weight"), M, d, d,
-                       out_b=fp.g_ptr(pre + "out_proj.bias"))
+            self.wgrad(ptr(drm), ptr(a[f"ctx{l}"]), 0, M, d, d, linear=[pre + "out_proj"])
             self.gemm(ptr(drm), ptr(w[f"oT{l}"]), ptr(g["dctx"]), M, d, d)
             call("eg_attention_bwd", ptr(a[f"qkv{l}"]), ptr(a[f"ctx{l}"]), ptr(g["dctx"]), ptr(a[f"lse{l}"]), ptr(g["dqkv"]),
                  NB, S, H, kv_shift, self.dtype, p, site_attn, self.st_ptr, st)
-            self.wgrad(ptr(g["dqkv"]), ptr(x_in), 0, M, 3 * d, d,
-                       split_out=[(fp.g_ptr(n + ".weight"), i * d, d) for i, n in enumerate(names)],
-                       out_b=[(fp.g_ptr(n + ".bias"), i * d, d) for i, n in enumerate(names)])
+            self.wgrad(ptr(g["dqkv"]), ptr(x_in), 0, M, 3 * d, d, linear=names)
             self.gemm(ptr(g["dqkv"]), ptr(w[f"qkvT{l}"]), ptr(dx_out), M, d, 3 * d, residual=ptr(dr))
 
         if cfg.use_cross_attention:
@@ -529,11 +545,9 @@ class Engine:
             self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", g["dr"], g["drm"] if has_drop else None,
                         d1=(p, sites["ffn_b"]), d2=(p, sites["drop2"]))
             drm = g["drm"] if has_drop else g["dr"]
-            self.wgrad(ptr(drm), ptr(a[f"hff{l}"]), fp.g_ptr(pre + "ffn.linear2.weight"), M, d, F,
-                       out_b=fp.g_ptr(pre + "ffn.linear2.bias"))
+            self.wgrad(ptr(drm), ptr(a[f"hff{l}"]), 0, M, d, F, linear=[pre + "ffn.linear2"])
             self.gemm(ptr(drm), ptr(w[f"w2T{l}"]), ptr(g["dh"]), M, F, d, gate=ptr(a[f"hff{l}"]), gate_scale=sc)
-            self.wgrad(ptr(g["dh"]), ptr(a[f"y1_{l}"]), fp.g_ptr(pre + "ffn.linear1.weight"), M, F, d,
-                       out_b=fp.g_ptr(pre + "ffn.linear1.bias"))
+            self.wgrad(ptr(g["dh"]), ptr(a[f"y1_{l}"]), 0, M, F, d, linear=[pre + "ffn.linear1"])
             self.gemm(ptr(g["dh"]), ptr(w[f"w1T{l}"]), ptr(g["dy1"]), M, d, F, residual=ptr(g["dr"]))
             self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", g["dr"], g["drm"] if has_drop else None,
                         d1=(p, sites["drop1"]))

@@ -217,12 +217,10 @@ def backward(model, eng: Engine, dseq):
         # tokens are shared by both streams: their gradient is the sum of the two sequences' rows
         call("eg_rows_gather_gate", ptr(dseq), 0, ptr(g["ib_dtok"]), rowmap(d), B, S, d, ntok, 1, B, 1.0, dt, st)
         call("eg_batch_rowsum", ptr(g["ib_dtok"]), fp.g_ptr(pre + "type_embedding"), B, ntok, d, ntok, dt, st)
-        eng.wgrad(ptr(g["ib_dtok"]), ptr(a["ib_h"]), fp.g_ptr(pre + "bottleneck.3.weight"), M, d, 64,
-                  out_b=fp.g_ptr(pre + "bottleneck.3.bias"))
+        eng.wgrad(ptr(g["ib_dtok"]), ptr(a["ib_h"]), 0, M, d, 64, linear=[pre + "bottleneck.3"])
         eng.gemm(ptr(g["ib_dtok"]), ptr(w["ib3T"]), ptr(g["ib_dh"]), M, 64, d)
         call("eg_gelu_bwd", ptr(a["ib_u"]), ptr(g["ib_dh"]), ptr(g["ib_du"]), M * 64, dt, p01, SITE_IBSTOK, eng.st_ptr, st)
-        eng.wgrad(ptr(g["ib_du"]), ptr(a["ib_in"]), fp.g_ptr(pre + "bottleneck.0.weight"), M, 64, E,
-                  out_b=fp.g_ptr(pre + "bottleneck.0.bias"))
+        eng.wgrad(ptr(g["ib_du"]), ptr(a["ib_in"]), 0, M, 64, E, linear=[pre + "bottleneck.0"])
         if cfg.ibs_instance_norm:
             eng.gemm(ptr(g["ib_du"]), ptr(w["ib0T"]), ptr(g["ib_dxn"]), M, E, 64)
             call("eg_affine_grad", ptr(g["ib_dxn"]), ptr(a["ib_xhat"]), fp.g_ptr(pre + "instance_norm.weight"),
@@ -230,7 +228,7 @@ def backward(model, eng: Engine, dseq):
     elif cfg.use_ibs:
         pre = "ibs_generator.proj."
         call("eg_rows_gather_gate", ptr(dseq), 0, ptr(g["ig_dtok"]), rowmap(d), B, S, d, 1, 1, B, 1.0, dt, st)
-        eng.wgrad(ptr(g["ig_dtok"]), ptr(a["ig_h"]), fp.g_ptr(pre + "3.weight"), B, d, 2 * d, out_b=fp.g_ptr(pre + "3.bias"))
+        eng.wgrad(ptr(g["ig_dtok"]), ptr(a["ig_h"]), 0, B, d, 2 * d, linear=[pre + "3"])
         eng.gemm(ptr(g["ig_dtok"]), ptr(w["ig3T"]), ptr(g["ig_dh"]), B, 2 * d, d, gate=ptr(a["ig_h"]), gate_scale=sc01)
         eng.wgrad(ptr(g["ig_dh"]), ptr(a["ig_featp"]), fp.g_ptr(pre + "0.weight"), B, 2 * d, 64, out_b=fp.g_ptr(pre + "0.bias"),
                   conv=(28, 1, 28))
@@ -239,11 +237,9 @@ def backward(model, eng: Engine, dseq):
         F, nfr, Hp, Wp, nimg, rows = sp["F"], sp["nfr"], sp["Hp"], sp["Wp"], sp["nimg"], sp["rows"]
         off = (1 + n_ibs) * d * es
         dmap = rowmap(d, S * d, Cn)
-        eng.wgrad(ptr(dseq) + off, ptr(a["sp_hp0"]), fp.g_ptr(pre + "proj.3.weight"), nimg, d, 2 * d, y=dmap,
-                  out_b=fp.g_ptr(pre + "proj.3.bias"))
+        eng.wgrad(ptr(dseq) + off, ptr(a["sp_hp0"]), 0, nimg, d, 2 * d, y=dmap, linear=[pre + "proj.3"])
         eng.gemm(ptr(dseq) + off, ptr(w["spp3T"]), ptr(g["sp_dhp0"]), nimg, 2 * d, d, a=dmap, gate=ptr(a["sp_hp0"]), gate_scale=sc01)
-        eng.wgrad(ptr(g["sp_dhp0"]), ptr(a["sp_pooled"]), fp.g_ptr(pre + "proj.0.weight"), nimg, 2 * d, 1024,
-                  out_b=fp.g_ptr(pre + "proj.0.bias"))
+        eng.wgrad(ptr(g["sp_dhp0"]), ptr(a["sp_pooled"]), 0, nimg, 2 * d, 1024, linear=[pre + "proj.0"])
         eng.gemm(ptr(g["sp_dhp0"]), ptr(w["spp0T"]), ptr(g["sp_dpooled"]), nimg, 1024, 2 * d)
         call("eg_spec_avgpool_bwd", ptr(a["sp_out2"]), ptr(g["sp_dpooled"]), ptr(g["sp_d2"]), nimg, Hp, Wp, dt, st)
         row32, row64 = (Wp + 4) * 32, (Wp + 4) * 64

@@ -117,8 +117,9 @@ int eg_gemm_nt(const eg_gemm_desc* d, void* stream);
  * eg_gemm_tn — weight-gradient product  dW[N,K] = sum_m dY[m,n] * X[m,k]  (fp32 result)
  *   replaces autograd's grad_weight of every Linear / Conv1d above.  Reads both operands row-major
  *   (rows = the reduction index) and transposes on the LDS read (ds_read_b64_tr_b16).  The reduction over
- *   M is split over `splits` workgroups; partials [splits, N, K] fp32 go to `partial` and
- *   eg_reduce_partials sums them (deterministic, no atomics).
+ *   M is split over `splits` workgroups; partial slabs [splits, slab] fp32 go to `partial` and
+ *   eg_reduce_partials sums them (deterministic, no atomics).  With has_bias the column sums of dY (the bias
+ *   gradient) are produced by the same launch; slab = (N/part_rows) * (part_rows*K + part_rows).
  * ------------------------------------------------------------------------------------------- */
 typedef struct eg_gemm_tn_desc {
   const void* dY; /* [M, N] rows addressed by `y` */
@@ -128,6 +129,8 @@ typedef struct eg_gemm_tn_desc {
   int32_t M, N, K, splits;
   int32_t dtype;
   int64_t x_tile_stride; /* 0/128 = contiguous X rows; else elements between consecutive 128-column tiles */
+  int32_t part_rows;     /* 0 = N.  One split's slab is N/part_rows parts of [part_rows x K | part_rows bias sums]: */
+  int32_t has_bias;      /* the layout of consecutive (weight, bias) parameters, so ONE eg_reduce_partials writes both */
 } eg_gemm_tn_desc;
 int eg_gemm_tn(const eg_gemm_tn_desc* d, void* stream);
 /* out[i] = (accumulate ? out[i] : 0) + sum_s partial[s*split_stride + i]; used for dW, db, LayerNorm dgamma/dbeta */
