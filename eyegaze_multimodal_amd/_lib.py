@@ -43,6 +43,11 @@ class GemmDesc(C.Structure):
                 ("gate_scale", C.c_float), ("a_seg_len", C.c_int32), ("a_seg_stride", C.c_int64)]
 
 
+class PackEntry(C.Structure):
+    _fields_ = [("src", C.c_uint64), ("dst", C.c_uint64), ("rows", C.c_int32), ("cols", C.c_int32), ("ldd", C.c_int32),
+                ("mode", C.c_int32), ("blk0", C.c_int32), ("nblk", C.c_int32)]
+
+
 class GemmTNDesc(C.Structure):
     _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("partial", C.c_void_p), ("y", RowMap), ("x", RowMap),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("splits", C.c_int32), ("dtype", C.c_int32),
@@ -55,6 +60,7 @@ _P, _I, _L, _F, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 SIGNATURES = {
     "eg_device_info": [C.POINTER(C.c_int), C.c_char_p, _I],
     "eg_window_pack": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "eg_pack_table": [_P, _I, _I, _I, _P],
     "eg_cast": [_P, _P, _L, _I, _P],
     "eg_transpose_cast": [_P, _P, _I, _I, _I, _I, _P],
     "eg_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -10,7 +10,7 @@ namespace {
 
 constexpr int BM = 128, BN = 128;
 constexpr int CT_PITCH = 132;                      // fp32 epilogue tile pitch (floats): 128 + 4
-constexpr int NT_LDS_BYTES = BM * CT_PITCH * 4;    // 67584 >= 2 * 32 KiB staging
+constexpr int NT_LDS_BYTES = 64 * CT_PITCH * 4;    // 33792 B: one 32 KiB staging tile / half of the fp32 epilogue image
 
 template <typename T>
 struct GemmNT {
@@ -76,9 +76,11 @@ __device__ __forceinline__ void mma_ktile<float>(const char* bufA, const char* b
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT<T> p) {
+__global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmNT<T> p) {
+  // 3 workgroups per CU: ONE 32 KiB LDS staging tile (the next K-tile waits in registers) and an epilogue that
+  // passes the two 64-row halves of the tile through a 33 KiB fp32 LDS image one after the other.  The small-K
+  // products of this model are latency-bound, so resident waves (12 per CU) matter more than barrier count.
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int EPB = 16 / sizeof(T);  // elements per 16-B chunk
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int bid = xcd_remap(blockIdx.x, p.nblocks);
@@ -104,23 +106,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT<T> p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // epilogue operands (residual / gate rows of this thread's 8 output chunks) are requested NOW, so their HBM
-  // latency hides under the K loop instead of serialising the epilogue (16-bit types: 8 x 16 B each)
-  constexpr bool kPrefetchEpi = sizeof(T) == 2;
-  const int ech = tid & 15, en = n0 + ech * 8;
-  u32x4 pres[8], pgate[8];
-  if (kPrefetchEpi) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + (tid >> 4) + 16 * i;
-      const bool ok = m < p.M && en < p.N;
-      pres[i] = (u32x4){0u, 0u, 0u, 0u};
-      pgate[i] = (u32x4){0u, 0u, 0u, 0u};
-      if (ok && p.residual) pres[i] = *(const u32x4*)(p.residual + row_off(p.r, m) + en);
-      if (ok && p.gate) pgate[i] = *(const u32x4*)(p.gate + row_off(p.c, m) + en);
-    }
-  }
-
   const int nk = p.K / (128 / (int)sizeof(T));
   // A rows may consist of several equally long segments (2-D convolution windows): K-tile kt starts at koff(kt)
   auto koff = [&](int kt) -> size_t {
@@ -134,16 +119,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT<T> p) {
     ra[i] = *(const u32x4*)(ap[i]);
     rw[i] = *(const u32x4*)(wp[i]);
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    *(u32x4*)(smem + soff + i * 4096) = ra[i];
-    *(u32x4*)(smem + 16384 + soff + i * 4096) = rw[i];
-  }
-  __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nk;
-    if (more) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(u32x4*)(smem + soff + i * 4096) = ra[i];
+      *(u32x4*)(smem + 16384 + soff + i * 4096) = rw[i];
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
       const size_t ka = koff(kt + 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -151,29 +134,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT<T> p) {
         rw[i] = *(const u32x4*)(wp[i] + (size_t)(kt + 1) * 128);
       }
     }
-    mma_ktile<T>(smem + cur * 32768, smem + cur * 32768 + 16384, wm, wn, lane, acc);
-    if (more) {
-      char* nb = smem + (cur ^ 1) * 32768;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *(u32x4*)(nb + soff + i * 4096) = ra[i];
-        *(u32x4*)(nb + 16384 + soff + i * 4096) = rw[i];
-      }
-    }
+    mma_ktile<T>(smem, smem + 16384, wm, wn, lane, acc);
     __syncthreads();
   }
 
-  // epilogue: accumulators -> fp32 LDS tile -> row-wise 8-element chunks with fused bias/act/gate/dropout/residual
+  // epilogue: accumulators -> fp32 LDS image (64 rows at a time) -> row-wise 8-element chunks with fused
+  // bias / act / gate / dropout / second output / residual
   float* ct = (float*)smem;
-  {
-    const int l15 = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-        *(f32x4*)(ct + (wm * 64 + mi * 16 + l15) * CT_PITCH + wn * 64 + ni * 16 + 4 * g) = acc[ni][mi];
-  }
-  __syncthreads();
   uint32_t seed_lo = 0, seed_hi = 0;
   if (p.d1.thresh | p.d2.thresh) {
     seed_lo = p.st->seed_lo;
@@ -181,46 +148,57 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT<T> p) {
   }
   const int ch = tid & 15;
   const int n = n0 + ch * 8;
-  if (n < p.N) {
-    float bv[8];
+  float bv[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bv[j] = 0.f;
-    if (p.bias) load8(p.bias + n, bv);
+  for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+  if (p.bias && n < p.N) load8(p.bias + n, bv);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = (tid >> 4) + 16 * i;
-      const int m = m0 + row;
-      if (m >= p.M) continue;
-      float v[8];
-      load8(ct + row * CT_PITCH + ch * 8, v);
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+      const int l15 = lane & 15, g = lane >> 4;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bv[j], p.act);
-      const long long coff = row_off(p.c, m) + n;
-      if (p.gate) {
-        float gv[8];
-        if (kPrefetchEpi) load8((const T*)&pgate[i], gv);
-        else load8(p.gate + coff, gv);
+      for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gv[j] > 0.f ? v[j] * p.gate_scale : 0.f;
-      }
-      if (p.d1.thresh | p.d2.thresh) {
-        const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          v[j] = eg_dropout(v[j], p.d1, seed_lo, seed_hi, idx + j);
-          v[j] = eg_dropout(v[j], p.d2, seed_lo, seed_hi, idx + j);
-        }
-      }
-      if (p.out_pre) store8(p.out_pre + row_off(p.pm, m) + n, v);
-      if (p.residual) {
-        float rv[8];
-        if (kPrefetchEpi) load8((const T*)&pres[i], rv);
-        else load8(p.residual + row_off(p.r, m) + n, rv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += rv[j];
-      }
-      store8(p.C + coff, v);
+        for (int mi = 0; mi < 4; ++mi)
+          *(f32x4*)(ct + (mi * 16 + l15) * CT_PITCH + wn * 64 + ni * 16 + 4 * g) = acc[ni][mi];
     }
+    __syncthreads();
+    if (n < p.N) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 4) + 16 * i;
+        const int m = m0 + half * 64 + row;
+        if (m >= p.M) continue;
+        float v[8];
+        load8(ct + row * CT_PITCH + ch * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bv[j], p.act);
+        const long long coff = row_off(p.c, m) + n;
+        if (p.gate) {
+          float gv[8];
+          load8(p.gate + coff, gv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gv[j] > 0.f ? v[j] * p.gate_scale : 0.f;
+        }
+        if (p.d1.thresh | p.d2.thresh) {
+          const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            v[j] = eg_dropout(v[j], p.d1, seed_lo, seed_hi, idx + j);
+            v[j] = eg_dropout(v[j], p.d2, seed_lo, seed_hi, idx + j);
+          }
+        }
+        if (p.out_pre) store8(p.out_pre + row_off(p.pm, m) + n, v);
+        if (p.residual) {
+          float rv[8];
+          load8(p.residual + row_off(p.r, m) + n, rv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += rv[j];
+        }
+        store8(p.C + coff, v);
+      }
+    }
+    __syncthreads();
   }
 }
 

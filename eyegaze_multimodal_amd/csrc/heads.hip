@@ -209,31 +209,44 @@ __global__ __launch_bounds__(256) void classifier_ce_bwd_kernel(const T* __restr
   }
 }
 
-// dW[c,k] = sum_b dlogits[b,c] h[b,k];  db[c] = sum_b dlogits[b,c]      grid = ncls blocks
+// dW[c,k] = sum_b dlogits[b,c] h[b,k];  db[c] = sum_b dlogits[b,c]      grid = (ncls, ceil(K/64)); 64 columns x 4 batch lanes
 template <typename T>
-__global__ void classifier_wgrad_kernel(const T* __restrict__ h, const float* __restrict__ dlogits,
-                                        float* __restrict__ dW, float* __restrict__ db, int B, int K, int ncls) {
-  const int c = blockIdx.x;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dlogits[(size_t)b * ncls + c] * Elem<T>::ld(h + (size_t)b * K + k);
-    dW[(size_t)c * K + k] = s;
+__global__ __launch_bounds__(256) void classifier_wgrad_kernel(const T* __restrict__ h, const float* __restrict__ dlogits,
+                                                               float* __restrict__ dW, float* __restrict__ db, int B, int K,
+                                                               int ncls) {
+  __shared__ float red[4][64], redb[4];
+  const int c = blockIdx.x, k = blockIdx.y * 64 + (threadIdx.x & 63), bl = threadIdx.x >> 6;
+  float s = 0.f, sb = 0.f;
+  for (int b = bl; b < B; b += 4) {
+    const float dl = dlogits[(size_t)b * ncls + c];
+    if (k < K) s = fmaf(dl, Elem<T>::ld(h + (size_t)b * K + k), s);
+    sb += dl;
   }
-  if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dlogits[(size_t)b * ncls + c];
-    db[c] = s;
+  red[bl][threadIdx.x & 63] = s;
+  if ((threadIdx.x & 63) == 0) redb[bl] = sb;
+  __syncthreads();
+  if (bl == 0) {
+    const int kk = threadIdx.x & 63;
+    if (k < K) dW[(size_t)c * K + k] = red[0][kk] + red[1][kk] + red[2][kk] + red[3][kk];
+    if (blockIdx.y == 0 && kk == 0) db[c] = redb[0] + redb[1] + redb[2] + redb[3];
   }
 }
 
 // out[s, :] = sum_b dseq[b, s, :]  (position-embedding gradient; row 0 is also the cls_token gradient)
+// grid = (rows, ceil(D/64)); 64 columns x 4 batch lanes per block
 template <typename T>
-__global__ void batch_rowsum_kernel(const T* __restrict__ dseq, float* __restrict__ out, int NB, int S, int D) {
-  const int s = blockIdx.x;
-  for (int n = threadIdx.x; n < D; n += blockDim.x) {
-    float a = 0.f;
-    for (int b = 0; b < NB; ++b) a += Elem<T>::ld(dseq + ((size_t)b * S + s) * D + n);
-    out[(size_t)s * D + n] = a;
+__global__ __launch_bounds__(256) void batch_rowsum_kernel(const T* __restrict__ dseq, float* __restrict__ out, int NB, int S,
+                                                           int D) {
+  __shared__ float red[4][64];
+  const int s = blockIdx.x, n = blockIdx.y * 64 + (threadIdx.x & 63), bl = threadIdx.x >> 6;
+  float a = 0.f;
+  if (n < D)
+    for (int b = bl; b < NB; b += 4) a += Elem<T>::ld(dseq + ((size_t)b * S + s) * D + n);
+  red[bl][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (bl == 0 && n < D) {
+    const int c = threadIdx.x & 63;
+    out[(size_t)s * D + n] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
   }
 }
 
@@ -399,9 +412,9 @@ extern "C" int eg_classifier_ce_bwd(const void* h, const float* W, const float* 
   dim3 grid((B + 3) / 4);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(classifier_ce_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)h, W, logits, (const long long*)labels, gloss, glogits, dlogits, (bf16_t*)dh, B, K, ncls, use_gate, gate_scale);
-             hipLaunchKernelGGL(classifier_wgrad_kernel<bf16_t>, dim3(ncls), dim3(256), 0, s, (const bf16_t*)h, dlogits, dW, db, B, K, ncls),
+             hipLaunchKernelGGL(classifier_wgrad_kernel<bf16_t>, dim3(ncls, (K + 63) / 64), dim3(256), 0, s, (const bf16_t*)h, dlogits, dW, db, B, K, ncls),
              hipLaunchKernelGGL(classifier_ce_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)h, W, logits, (const long long*)labels, gloss, glogits, dlogits, (float*)dh, B, K, ncls, use_gate, gate_scale);
-             hipLaunchKernelGGL(classifier_wgrad_kernel<float>, dim3(ncls), dim3(256), 0, s, (const float*)h, dlogits, dW, db, B, K, ncls),
+             hipLaunchKernelGGL(classifier_wgrad_kernel<float>, dim3(ncls, (K + 63) / 64), dim3(256), 0, s, (const float*)h, dlogits, dW, db, B, K, ncls),
              "eg_classifier_ce_bwd");
   EG_LAUNCH_CHECK("classifier_ce_bwd");
   return 0;
@@ -411,8 +424,8 @@ extern "C" int eg_batch_rowsum(const void* dseq, float* out, int NB, int S, int 
   EG_CHECK(dseq && out && NB > 0 && rows > 0 && rows <= S, "eg_batch_rowsum: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(batch_rowsum_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)dseq, out, NB, S, D),
-             hipLaunchKernelGGL(batch_rowsum_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)dseq, out, NB, S, D),
+             hipLaunchKernelGGL(batch_rowsum_kernel<bf16_t>, dim3(rows, (D + 63) / 64), dim3(256), 0, s, (const bf16_t*)dseq, out, NB, S, D),
+             hipLaunchKernelGGL(batch_rowsum_kernel<float>, dim3(rows, (D + 63) / 64), dim3(256), 0, s, (const float*)dseq, out, NB, S, D),
              "eg_batch_rowsum");
   EG_LAUNCH_CHECK("batch_rowsum");
   return 0;

@@ -110,7 +110,72 @@ __global__ void pack_convT_weight_kernel(const float* __restrict__ w, T* __restr
   Elem<T>::st(dst + i, v);
 }
 
+// table-driven parameter staging: ONE launch re-casts / transposes every weight of the model.
+// mode 0: dst[i] = cast(src[i]) over rows*cols contiguous elements; mode 1: dst[c*ldd + r] = cast(src[r*cols + c]);
+// mode 2: like 0 but the destination is fp32 (bias vectors gathered into fused buffers).  Each block handles one
+// 32x32 tile (mode 1) or 1024 elements (modes 0/2); blk0 is the entry's first block.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_table_kernel(const eg_pack_entry* __restrict__ tab, int nent) {
+  __shared__ float tile[32][33];
+  __shared__ int ent_s;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = nent - 1;
+    while (lo < hi) {  // last entry with blk0 <= blockIdx.x
+      const int mid = (lo + hi + 1) >> 1;
+      if (tab[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    ent_s = lo;
+  }
+  __syncthreads();
+  const eg_pack_entry e = tab[ent_s];
+  const int lb = blockIdx.x - e.blk0;
+  const float* src = (const float*)e.src;
+  if (e.mode == 1) {
+    const int tiles_c = (e.cols + 31) / 32;
+    const int r0 = (lb / tiles_c) * 32, c0 = (lb % tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+      const int r = r0 + i, c = c0 + tx;
+      tile[i][tx] = (r < e.rows && c < e.cols) ? src[(size_t)r * e.cols + c] : 0.f;
+    }
+    __syncthreads();
+    T* dst = (T*)e.dst;
+    for (int i = ty; i < 32; i += 8) {
+      const int c = c0 + i, r = r0 + tx;
+      if (c < e.cols && r < e.rows) Elem<T>::st(dst + (size_t)c * e.ldd + r, tile[tx][i]);
+    }
+  } else {
+    const long long n = (long long)e.rows * e.cols;
+    const long long i0 = (long long)lb * 1024 + threadIdx.x * 4;
+    if (e.mode == 2) {
+      float* dst = (float*)e.dst;
+      for (long long i = i0; i < min(n, i0 + 4); ++i) dst[i] = src[i];
+    } else {
+      T* dst = (T*)e.dst;
+      if (i0 + 4 <= n) {
+        float v[4];
+        load4(src + i0, v);
+        store4(dst + i0, v);
+      } else {
+        for (long long i = i0; i < n; ++i) Elem<T>::st(dst + i, src[i]);
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int eg_pack_table(const eg_pack_entry* table, int nentries, int total_blocks, int dtype, void* stream) {
+  EG_CHECK(table && nentries > 0 && total_blocks > 0, "eg_pack_table: bad arguments");
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(pack_table_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, nentries);
+  else if (dtype == EG_F32)
+    hipLaunchKernelGGL(pack_table_kernel<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, nentries);
+  else
+    return eg_fail("eg_pack_table: bad dtype %d", dtype);
+  EG_LAUNCH_CHECK("pack_table");
+  return 0;
+}
 
 extern "C" int eg_window_pack(const float* x, void* xt, int NB, int C, int T, int Cp, int pad_front, int Tp, int dtype,
                               void* stream) {

@@ -130,6 +130,8 @@ class Engine:
         self.probes = {}   # tag -> (start_event, end_event) recorded around that launch (bench.py roofline probe)
         self._alloc()
         self.packed_version = -1
+        self._recording = False
+        self._plan = []
 
     # ------------------------------------------------------------------------------------------
     def _t(self, *shape, dtype=None):
@@ -349,49 +351,84 @@ class Engine:
 
     def ln_bwd(self, dy, x, stats, gname, dx, dx_drop=None, d1=(0.0, 0), d2=(0.0, 0)):
         d = self.cfg.d_model
-        nblk = max(64, min(2048, self.M // 16))
+        nblk = 512
         call("eg_layernorm_bwd", ptr(dy), ptr(x), ptr(stats), self.fp.p_ptr(gname + ".weight"), ptr(dx), ptr(dx_drop),
              ptr(self.g["lnpart"]), nblk, self.M, d, self.dtype, d1[0], d1[1], d2[0], d2[1], self.st_ptr, self.stream)
         lp = ptr(self.g["lnpart"])
-        call("eg_reduce_partials", lp, self.fp.g_ptr(gname + ".weight"), d, nblk, 2 * d, 0, self.stream)
-        call("eg_reduce_partials", lp + 4 * d, self.fp.g_ptr(gname + ".bias"), d, nblk, 2 * d, 0, self.stream)
+        if self.fp.offsets[gname + ".bias"] == self.fp.offsets[gname + ".weight"] + d:   # (gain | bias) back to back
+            call("eg_reduce_partials", lp, self.fp.g_ptr(gname + ".weight"), 2 * d, nblk, 2 * d, 0, self.stream)
+        else:
+            call("eg_reduce_partials", lp, self.fp.g_ptr(gname + ".weight"), d, nblk, 2 * d, 0, self.stream)
+            call("eg_reduce_partials", lp + 4 * d, self.fp.g_ptr(gname + ".bias"), d, nblk, 2 * d, 0, self.stream)
 
     # ------------------------------------------------------------------------------------------
     # parameter staging
     # ------------------------------------------------------------------------------------------
+    # table-driven staging: cast / transpose entries are recorded once and replayed as ONE launch per step
+    def p_cast(self, src, dst, n):
+        if self._recording:
+            self._plan.append((src, dst, 1, n, 0, 0))
+
+    def p_copy(self, src, dst, n):
+        if self._recording:
+            self._plan.append((src, dst, 1, n, 0, 2))
+
+    def p_transpose(self, src, dst, R, Cc, ldd):
+        if self._recording:
+            self._plan.append((src, dst, R, Cc, ldd, 1))
+
     def pack_params(self):
+        key = (self.fp.flat.data_ptr(), self.stream)
+        if getattr(self, "_plan_key", None) != key[0]:
+            self._plan, self._recording = [], True
+            self._pack_body()
+            self._recording = False
+            ents = (L.PackEntry * len(self._plan))()
+            blk = 0
+            for e, (src, dst, R, Cc, ldd, mode) in zip(ents, self._plan):
+                nb = ((R + 31) // 32) * ((Cc + 31) // 32) if mode == 1 else (R * Cc + 1023) // 1024
+                e.src, e.dst, e.rows, e.cols, e.ldd, e.mode, e.blk0, e.nblk = src, dst, R, Cc, ldd, mode, blk, nb
+                blk += nb
+            raw = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8)
+            self._plan_dev = raw.to(self.device)
+            self._plan_n, self._plan_blocks, self._plan_key = len(self._plan), blk, key[0]
+        else:
+            self._pack_body()
+        call("eg_pack_table", ptr(self._plan_dev), self._plan_n, self._plan_blocks, self.dtype, self.stream)
+
+    def _pack_body(self):
         cfg, d, F, fp, w, dt, st = self.cfg, self.cfg.d_model, self.cfg.d_ff, self.fp, self.w, self.dtype, self.stream
         call("eg_pack_conv_weight", fp.p_ptr("temporal_conv.convs.0.weight"), ptr(w["conv0"]), d, self.C, self.k, self.Cp,
              self.K0, dt, st)
         call("eg_pack_conv_weight", fp.p_ptr("temporal_conv.convs.1.weight"), ptr(w["conv1"]), d, d, self.k, d, self.k * d,
              dt, st)
         call("eg_pack_convT_weight", fp.p_ptr("temporal_conv.convs.1.weight"), ptr(w["conv1T"]), d, d, self.k, self.s, dt, st)
-        call("eg_cast", fp.p_ptr("pos_embed.pos_embed.weight"), ptr(w["pos"]), cfg.max_len * d, dt, st)
+        self.p_cast(fp.p_ptr("pos_embed.pos_embed.weight"), ptr(w["pos"]), cfg.max_len * d)
 
         def attn_pack(pre, l):
             for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
-                call("eg_cast", fp.p_ptr(f"{pre}{n}.weight"), ptr(w[f"qkv{l}"]) + i * d * d * self.es, d * d, dt, st)
-                call("eg_transpose_cast", fp.p_ptr(f"{pre}{n}.weight"), ptr(w[f"qkvT{l}"]) + i * d * self.es, d, d, 3 * d, dt, st)
-                call("eg_cast", fp.p_ptr(f"{pre}{n}.bias"), ptr(w[f"bqkv{l}"]) + 4 * i * d, d, EG_F32, st)
-            call("eg_cast", fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"o{l}"]), d * d, dt, st)
-            call("eg_transpose_cast", fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"oT{l}"]), d, d, d, dt, st)
+                self.p_cast(fp.p_ptr(f"{pre}{n}.weight"), ptr(w[f"qkv{l}"]) + i * d * d * self.es, d * d)
+                self.p_transpose(fp.p_ptr(f"{pre}{n}.weight"), ptr(w[f"qkvT{l}"]) + i * d * self.es, d, d, 3 * d)
+                self.p_copy(fp.p_ptr(f"{pre}{n}.bias"), ptr(w[f"bqkv{l}"]) + 4 * i * d, d)
+            self.p_cast(fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"o{l}"]), d * d)
+            self.p_transpose(fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"oT{l}"]), d, d, d)
 
         for l in range(cfg.num_layers):
             pre = f"encoder.layers.{l}."
             attn_pack(pre + "mha.", l)
-            call("eg_cast", fp.p_ptr(pre + "ffn.linear1.weight"), ptr(w[f"w1{l}"]), F * d, dt, st)
-            call("eg_transpose_cast", fp.p_ptr(pre + "ffn.linear1.weight"), ptr(w[f"w1T{l}"]), F, d, F, dt, st)
-            call("eg_cast", fp.p_ptr(pre + "ffn.linear2.weight"), ptr(w[f"w2{l}"]), d * F, dt, st)
-            call("eg_transpose_cast", fp.p_ptr(pre + "ffn.linear2.weight"), ptr(w[f"w2T{l}"]), d, F, d, dt, st)
+            self.p_cast(fp.p_ptr(pre + "ffn.linear1.weight"), ptr(w[f"w1{l}"]), F * d)
+            self.p_transpose(fp.p_ptr(pre + "ffn.linear1.weight"), ptr(w[f"w1T{l}"]), F, d, F)
+            self.p_cast(fp.p_ptr(pre + "ffn.linear2.weight"), ptr(w[f"w2{l}"]), d * F)
+            self.p_transpose(fp.p_ptr(pre + "ffn.linear2.weight"), ptr(w[f"w2T{l}"]), d, F, d)
         if cfg.use_cross_attention:
             attn_pack("cross_attn.cross_attn.", "x")
-        call("eg_cast", fp.p_ptr("symmetric_fusion.proj.weight"), ptr(w["sf"]), 3 * d * d, dt, st)
-        call("eg_transpose_cast", fp.p_ptr("symmetric_fusion.proj.weight"), ptr(w["sfT"]), d, 3 * d, d, dt, st)
-        call("eg_cast", fp.p_ptr("classifier.0.weight"), ptr(w["c0"]), 3 * d * d, dt, st)
-        call("eg_transpose_cast", fp.p_ptr("classifier.0.weight"), ptr(w["c0T"]), d, 3 * d, d, dt, st)
+        self.p_cast(fp.p_ptr("symmetric_fusion.proj.weight"), ptr(w["sf"]), 3 * d * d)
+        self.p_transpose(fp.p_ptr("symmetric_fusion.proj.weight"), ptr(w["sfT"]), d, 3 * d, d)
+        self.p_cast(fp.p_ptr("classifier.0.weight"), ptr(w["c0"]), 3 * d * d)
+        self.p_transpose(fp.p_ptr("classifier.0.weight"), ptr(w["c0T"]), d, 3 * d, d)
         if cfg.use_ibs:
-            call("eg_cast", fp.p_ptr("ibs_classifier.0.weight"), ptr(w["i0"]), (d // 2) * d, dt, st)
-            call("eg_transpose_cast", fp.p_ptr("ibs_classifier.0.weight"), ptr(w["i0T"]), d // 2, d, w["i0T"].shape[1], dt, st)
+            self.p_cast(fp.p_ptr("ibs_classifier.0.weight"), ptr(w["i0"]), (d // 2) * d)
+            self.p_transpose(fp.p_ptr("ibs_classifier.0.weight"), ptr(w["i0T"]), d // 2, d, w["i0T"].shape[1])
         self.model._pack_extra(self)
 
     # ------------------------------------------------------------------------------------------

@@ -121,24 +121,24 @@ def pack(model, eng: Engine):
         pre = "spectrogram_generator."
         call("eg_pack_conv2d_weight", fp.p_ptr(pre + "spec_conv.3.weight"), ptr(w["spc2"]), 64, 32, 0, dt, st)
         call("eg_pack_conv2d_weight", fp.p_ptr(pre + "spec_conv.3.weight"), ptr(w["spc2T"]), 64, 32, 1, dt, st)
-        call("eg_cast", fp.p_ptr(pre + "proj.0.weight"), ptr(w["spp0"]), 2 * d * 1024, dt, st)
-        call("eg_transpose_cast", fp.p_ptr(pre + "proj.0.weight"), ptr(w["spp0T"]), 2 * d, 1024, 2 * d, dt, st)
-        call("eg_cast", fp.p_ptr(pre + "proj.3.weight"), ptr(w["spp3"]), d * 2 * d, dt, st)
-        call("eg_transpose_cast", fp.p_ptr(pre + "proj.3.weight"), ptr(w["spp3T"]), d, 2 * d, d, dt, st)
+        eng.p_cast(fp.p_ptr(pre + "proj.0.weight"), ptr(w["spp0"]), 2 * d * 1024)
+        eng.p_transpose(fp.p_ptr(pre + "proj.0.weight"), ptr(w["spp0T"]), 2 * d, 1024, 2 * d)
+        eng.p_cast(fp.p_ptr(pre + "proj.3.weight"), ptr(w["spp3"]), d * 2 * d)
+        eng.p_transpose(fp.p_ptr(pre + "proj.3.weight"), ptr(w["spp3T"]), d, 2 * d, d)
     if cfg.use_ibs and cfg.use_robust_ibs:
         pre, ntok, E = "ibs_tokenizer.", cfg.num_ibs_tokens, eng.C * eng.C
-        call("eg_cast", fp.p_ptr(pre + "bottleneck.0.weight"), ptr(w["ib0"]), 64 * E, dt, st)
-        call("eg_transpose_cast", fp.p_ptr(pre + "bottleneck.0.weight"), ptr(w["ib0T"]), 64, E, 64, dt, st)
-        call("eg_cast", fp.p_ptr(pre + "bottleneck.3.weight"), ptr(w["ib3"]), d * 64, dt, st)
-        call("eg_transpose_cast", fp.p_ptr(pre + "bottleneck.3.weight"), ptr(w["ib3T"]), d, 64, d, dt, st)
+        eng.p_cast(fp.p_ptr(pre + "bottleneck.0.weight"), ptr(w["ib0"]), 64 * E)
+        eng.p_transpose(fp.p_ptr(pre + "bottleneck.0.weight"), ptr(w["ib0T"]), 64, E, 64)
+        eng.p_cast(fp.p_ptr(pre + "bottleneck.3.weight"), ptr(w["ib3"]), d * 64)
+        eng.p_transpose(fp.p_ptr(pre + "bottleneck.3.weight"), ptr(w["ib3T"]), d, 64, d)
         # additive row table of the token GEMM: type_embedding[i] + pos[1 + i]   (D:909, A:120-126)
         call("eg_rows_bcast_f32", fp.p_ptr(pre + "type_embedding"), fp.p_ptr("pos_embed.pos_embed.weight"), ptr(w["ib_add"]), 1,
              1 + ntok, d, ntok, 1, 1, dt, st)
     elif cfg.use_ibs:
         pre = "ibs_generator.proj."
         call("eg_pack_conv_weight", fp.p_ptr(pre + "0.weight"), ptr(w["ig0"]), 2 * d, 28, 1, 28, 64, dt, st)
-        call("eg_cast", fp.p_ptr(pre + "3.weight"), ptr(w["ig3"]), d * 2 * d, dt, st)
-        call("eg_transpose_cast", fp.p_ptr(pre + "3.weight"), ptr(w["ig3T"]), d, 2 * d, d, dt, st)
+        eng.p_cast(fp.p_ptr(pre + "3.weight"), ptr(w["ig3"]), d * 2 * d)
+        eng.p_transpose(fp.p_ptr(pre + "3.weight"), ptr(w["ig3T"]), d, 2 * d, d)
 
 
 # ------------------------------------------------------------------------------------------------

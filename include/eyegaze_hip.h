@@ -78,6 +78,14 @@ int eg_window_pack(const float* x, void* xt, int NB, int C, int T, int Cp, int p
  *   eg_pack_convT_weight: backward-data weights of the stride-s conv, one matrix per output phase p:
  *                        dst[p][c][j*N + n] = w[n][c][s*(J-1-j) + p] (0 where the tap is > k-1), J = ceil(k/s)
  */
+/* eg_pack_table: all of the above casts / transposes of one model in ONE launch.  `table` is a DEVICE array; entry i owns
+ * blocks [blk0, blk0 + nblk): mode 0 cast (1024 elements per block), 1 transpose-cast (one 32x32 tile per block),
+ * 2 fp32 copy (fused bias vectors).  src / dst are absolute device addresses. */
+typedef struct eg_pack_entry {
+  uint64_t src, dst;
+  int32_t rows, cols, ldd, mode, blk0, nblk;
+} eg_pack_entry;
+int eg_pack_table(const eg_pack_entry* table, int nentries, int total_blocks, int dtype, void* stream);
 int eg_cast(const float* src, void* dst, int64_t n, int dtype, void* stream);
 int eg_transpose_cast(const float* src, void* dst, int R, int Cc, int ldd, int dtype, void* stream);
 int eg_pack_conv_weight(const float* w, void* dst, int N, int Cin, int k, int Cp, int Kp, int dtype, void* stream);
