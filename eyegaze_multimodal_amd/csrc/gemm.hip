@@ -222,8 +222,8 @@ struct GemmTN {
 __device__ __forceinline__ int tn_swz(int r) { return (((r & 3) | ((r >> 1) & 4)) << 1); }
 
 template <typename T> struct TNCfg;
-template <> struct TNCfg<bf16_t> { static constexpr int ROWB = 256; static constexpr int CHUNKS = 16; };
-template <> struct TNCfg<float> { static constexpr int ROWB = 512; static constexpr int CHUNKS = 32; };
+template <> struct TNCfg<bf16_t> { static constexpr int ROWB = 256; static constexpr int CHUNKS = 16; static constexpr int STAGE_ROWS = 64; };
+template <> struct TNCfg<float> { static constexpr int ROWB = 512; static constexpr int CHUNKS = 32; static constexpr int STAGE_ROWS = 32; };
 
 template <typename T>
 __device__ __forceinline__ void tn_mma(const char* bufY, const char* bufX, int wn, int wk, int lane, f32x4 (&acc)[4][4]);
@@ -309,13 +309,16 @@ __device__ __forceinline__ float tn_tile_colsum<float>(const char* bufY, int col
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN<T> p) {
+__global__ __launch_bounds__(256, 3) void gemm_tn_kernel(GemmTN<T> p) {
+  // 64 reduction rows per stage in ONE LDS buffer (the next stage waits in registers): 32 KiB (bf16) per workgroup,
+  // three workgroups per CU, 32 KiB of loads in flight per workgroup.
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROWB = TNCfg<T>::ROWB;          // bytes per LDS tile row (128 columns)
   constexpr int CHUNKS = TNCfg<T>::CHUNKS;      // 16-B chunks per row
   constexpr int EPC = 16 / (int)sizeof(T);      // elements per chunk
-  constexpr int TILEB = 32 * ROWB;              // one operand tile
-  constexpr int PER_THREAD = 32 * CHUNKS / 256; // chunks per thread per operand (2 bf16, 4 f32)
+  constexpr int RS = TNCfg<T>::STAGE_ROWS;      // reduction rows per stage (64 bf16 / 32 f32)
+  constexpr int TILEB = RS * ROWB;              // one operand tile
+  constexpr int PER_THREAD = RS * CHUNKS / 256; // chunks per thread per operand
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave >> 1, wn = wave & 1;
   const int split = blockIdx.x / p.tiles_nk;
@@ -357,21 +360,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN<T> p) {
       *(u32x4*)(buf + TILEB + off) = rx[i];
     }
   };
-  const int nt = (mend - mbeg + 31) / 32;
+  const int nt = (mend - mbeg + RS - 1) / RS;
   const bool do_bias = p.has_bias && (t % p.tiles_k) == 0;  // the k-tile-0 blocks see every dY row exactly once
   float bsum = 0.f;
-  if (nt > 0) {
-    load_tile(mbeg);
-    store_tile(smem);
-  }
-  __syncthreads();
+  if (nt > 0) load_tile(mbeg);
   for (int it = 0; it < nt; ++it) {
-    const int cur = it & 1;
-    const bool more = it + 1 < nt;
-    if (more) load_tile(mbeg + (it + 1) * 32);
-    tn_mma<T>(smem + cur * 2 * TILEB, smem + cur * 2 * TILEB + TILEB, wn, wk, lane, acc);
-    if (do_bias) bsum += tn_tile_colsum<T>(smem + cur * 2 * TILEB, tid & 127, tid >> 7);
-    if (more) store_tile(smem + (cur ^ 1) * 2 * TILEB);
+    store_tile(smem);
+    __syncthreads();
+    if (it + 1 < nt) load_tile(mbeg + (it + 1) * RS);
+#pragma unroll
+    for (int sub = 0; sub < RS / 32; ++sub) {
+      tn_mma<T>(smem + sub * 32 * ROWB, smem + TILEB + sub * 32 * ROWB, wn, wk, lane, acc);
+      if (do_bias) bsum += tn_tile_colsum<T>(smem + sub * 32 * ROWB, tid & 127, tid >> 7);
+    }
     __syncthreads();
   }
   // D[i = k][j = n]: lane holds 4 consecutive k (rows 4g+r) for column n = lane&15
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN<T> p) {
       }
     }
   if (do_bias) {
-    float* red = (float*)smem;  // the staging buffers are free after the loop's final barrier
+    float* red = (float*)smem;  // the staging buffer is free after the loop's final barrier
     red[tid] = bsum;
     __syncthreads();
     if (tid < 128) {
@@ -545,7 +546,7 @@ static int launch_gemm_tn(const eg_gemm_tn_desc* d, hipStream_t s) {
   p.y = to_rowmap(d->y); p.x = to_rowmap(d->x);
   p.M = d->M; p.N = d->N; p.K = d->K; p.splits = d->splits;
   int rps = (d->M + d->splits - 1) / d->splits;
-  p.rows_per_split = (rps + 31) / 32 * 32;
+  p.rows_per_split = (rps + 63) / 64 * 64;
   p.tiles_k = (d->K + 127) / 128;
   p.tiles_nk = p.tiles_k * ((d->N + 127) / 128);
   p.x_tile_stride = d->x_tile_stride > 0 ? d->x_tile_stride : 128;
@@ -553,7 +554,7 @@ static int launch_gemm_tn(const eg_gemm_tn_desc* d, hipStream_t s) {
   p.has_bias = d->has_bias ? 1 : 0;
   p.part_size = (long long)p.part_rows * d->K + (p.has_bias ? p.part_rows : 0);
   p.slab = (long long)(d->N / p.part_rows) * p.part_size;
-  const int lds = 4 * 32 * TNCfg<T>::ROWB;
+  const int lds = 2 * TNCfg<T>::STAGE_ROWS * TNCfg<T>::ROWB;
   hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(p.tiles_nk * d->splits), dim3(256), lds, s, p);
   EG_LAUNCH_CHECK("gemm_tn");
   return 0;

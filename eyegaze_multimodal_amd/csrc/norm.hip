@@ -139,6 +139,117 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
+// ---- D == 256 fast path: half a wave (32 lanes x 8 elements = 16-B accesses) per row, two rows per wave ----
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd256_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, T* __restrict__ y,
+                                                               float* __restrict__ stats, int M) {
+  const int lane = threadIdx.x & 63, l = lane & 31;
+  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+  const bool ok = row < M;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  if (ok) load8(x + (size_t)row * 256 + l * 8, v);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += v[e];
+  const float mean = half_sum(s) * (1.0f / 256.f);
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; q += d * d; }
+  const float rstd = rsqrtf(half_sum(q) * (1.0f / 256.f) + 1e-5f);
+  if (!ok) return;
+  float g[8], b[8], o[8];
+  load8(gamma + l * 8, g);
+  load8(beta + l * 8, b);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (v[e] - mean) * rstd * g[e] + b[e];
+  store8(y + (size_t)row * 256 + l * 8, o);
+  if (stats && l == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd256_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                               const float* __restrict__ stats,
+                                                               const float* __restrict__ gamma, T* __restrict__ dx,
+                                                               T* __restrict__ dx_drop, float* __restrict__ partial, int M,
+                                                               DropCfg d1, DropCfg d2, const eg_step_state* st) {
+  __shared__ float red[8][2][256];
+  const int lane = threadIdx.x & 63, l = lane & 31, hw = threadIdx.x >> 5;  // 8 half-waves per block
+  float g[8], dg[8], db[8];
+  load8(gamma + l * 8, g);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { dg[e] = 0.f; db[e] = 0.f; }
+  uint32_t seed_lo = 0, seed_hi = 0;
+  const bool drop = (d1.thresh | d2.thresh) != 0 && dx_drop != nullptr;
+  if (drop) { seed_lo = st->seed_lo; seed_hi = st->seed_hi; }
+  const int nrows = gridDim.x * 8;
+  // both halves of a wave must run the same trip count (the shuffles below are wave-wide)
+  const int trips = (M + nrows - 1) / nrows;
+  for (int it = 0; it < trips; ++it) {
+    const int row = it * nrows + blockIdx.x * 8 + hw;
+    const bool ok = row < M;
+    float xv[8], dv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { xv[e] = 0.f; dv[e] = 0.f; }
+    float mean = 0.f, rstd = 0.f;
+    if (ok) {
+      load8(x + (size_t)row * 256 + l * 8, xv);
+      load8(dy + (size_t)row * 256 + l * 8, dv);
+      mean = stats[2 * row];
+      rstd = stats[2 * row + 1];
+    }
+    float xh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      xh[e] = (xv[e] - mean) * rstd;
+      dg[e] += dv[e] * xh[e];
+      db[e] += dv[e];
+      const float dxh = dv[e] * g[e];
+      s1 += dxh;
+      s2 += dxh * xh[e];
+    }
+    const float c1 = half_sum(s1) * (1.0f / 256.f), c2 = half_sum(s2) * (1.0f / 256.f);
+    if (ok) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = rstd * (dv[e] * g[e] - c1 - xh[e] * c2);
+      store8(dx + (size_t)row * 256 + l * 8, o);
+      if (dx_drop) {
+        if (drop) {
+          const uint32_t idx = (uint32_t)row * 256u + (uint32_t)(l * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            o[e] = eg_dropout(o[e], d1, seed_lo, seed_hi, idx + e);
+            o[e] = eg_dropout(o[e], d2, seed_lo, seed_hi, idx + e);
+          }
+        }
+        store8(dx_drop + (size_t)row * 256 + l * 8, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[hw][0][l * 8 + e] = dg[e];
+    red[hw][1][l * 8 + e] = db[e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    const int which = i >> 8, n = i & 255;
+    float s = 0.f;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) s += red[h][which][n];
+    partial[(size_t)blockIdx.x * 512 + i] = s;
+  }
+}
+
 }  // namespace
 
 extern "C" int eg_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int D,
@@ -146,6 +257,17 @@ extern "C" int eg_layernorm_fwd(const void* x, const float* gamma, const float* 
   EG_CHECK(x && gamma && beta && y, "eg_layernorm_fwd: null pointer");
   EG_CHECK(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "eg_layernorm_fwd: D=%d must be a multiple of 4, <= 1024", D);
   dim3 grid((M + 3) / 4);
+  if (D == 256 && (dtype == EG_BF16 || dtype == EG_F32)) {
+    dim3 g8((M + 7) / 8);
+    if (dtype == EG_BF16)
+      hipLaunchKernelGGL(layernorm_fwd256_kernel<bf16_t>, g8, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta,
+                         (bf16_t*)y, stats, M);
+    else
+      hipLaunchKernelGGL(layernorm_fwd256_kernel<float>, g8, dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma, beta,
+                         (float*)y, stats, M);
+    EG_LAUNCH_CHECK("layernorm_fwd256");
+    return 0;
+  }
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma,
                        beta, (bf16_t*)y, stats, M, D);
@@ -167,6 +289,16 @@ extern "C" int eg_layernorm_bwd(const void* dy, const void* x, const float* stat
   EG_CHECK((drop1_p == 0.f && drop2_p == 0.f) || state, "eg_layernorm_bwd: dropout needs a step state");
   EG_CHECK((long long)M * D < (1ll << 32), "eg_layernorm_bwd: M*D exceeds the 32-bit dropout index");
   DropCfg d1 = make_drop(drop1_p, drop1_site), d2 = make_drop(drop2_p, drop2_site);
+  if (D == 256 && (dtype == EG_BF16 || dtype == EG_F32)) {
+    if (dtype == EG_BF16)
+      hipLaunchKernelGGL(layernorm_bwd256_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                         (const bf16_t*)x, stats, gamma, (bf16_t*)dx, (bf16_t*)dx_drop, partial, M, d1, d2, state);
+    else
+      hipLaunchKernelGGL(layernorm_bwd256_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
+                         (const float*)x, stats, gamma, (float*)dx, (float*)dx_drop, partial, M, d1, d2, state);
+    EG_LAUNCH_CHECK("layernorm_bwd256");
+    return 0;
+  }
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                        (const bf16_t*)x, stats, gamma, (bf16_t*)dx, (bf16_t*)dx_drop, partial, M, D, d1, d2, state);

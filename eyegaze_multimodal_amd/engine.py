@@ -308,7 +308,7 @@ class Engine:
                                        self.fp.offsets[n + ".bias"] == base + i * (P * K + P) + P * K
                                        for i, n in enumerate(linear))
         slab = N * K + (N if fused else 0)
-        splits = max(1, min((M + 127) // 128, (512 + tiles - 1) // tiles, self.tn_cap // slab))
+        splits = max(1, min((M + 127) // 128, (768 + tiles - 1) // tiles, self.tn_cap // slab))
         dsc = GemmTNDesc()
         dsc.dY, dsc.X, dsc.partial = dY, X, ptr(self.g["partial"])
         dsc.y = y or rowmap(N)
