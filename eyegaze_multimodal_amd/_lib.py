@@ -48,6 +48,17 @@ class PackEntry(C.Structure):
                 ("mode", C.c_int32), ("blk0", C.c_int32), ("nblk", C.c_int32)]
 
 
+class TNProblem(C.Structure):
+    _fields_ = [("dY", C.c_uint64), ("X", C.c_uint64), ("partial", C.c_uint64), ("ldy", C.c_int64), ("ldx", C.c_int64),
+                ("N", C.c_int32), ("K", C.c_int32), ("part_rows", C.c_int32), ("has_bias", C.c_int32), ("blk0", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
+class ReduceEntry(C.Structure):
+    _fields_ = [("partial", C.c_uint64), ("out", C.c_uint64), ("n", C.c_int64), ("stride", C.c_int64),
+                ("splits", C.c_int32), ("blk0", C.c_int32)]
+
+
 class GemmTNDesc(C.Structure):
     _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("partial", C.c_void_p), ("y", RowMap), ("x", RowMap),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("splits", C.c_int32), ("dtype", C.c_int32),
@@ -68,6 +79,8 @@ SIGNATURES = {
     "eg_gemm_nt": [C.POINTER(GemmDesc), _P],
     "eg_gemm_tn": [C.POINTER(GemmTNDesc), _P],
     "eg_reduce_partials": [_P, _P, _L, _I, _L, _I, _P],
+    "eg_gemm_tn_grouped": [_P, _I, _I, _I, _I, _I, _P],
+    "eg_reduce_table": [_P, _I, _I, _P],
     "eg_unpack_conv_wgrad": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eg_colsum": [_P, RowMap, _I, _I, _P, _I, _I, _P],
     "eg_layernorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],

@@ -309,10 +309,9 @@ __device__ __forceinline__ float tn_tile_colsum<float>(const char* bufY, int col
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 3) void gemm_tn_kernel(GemmTN<T> p) {
+__device__ __forceinline__ void tn_body(const GemmTN<T>& p, const int split, const int t, char* smem) {
   // 64 reduction rows per stage in ONE LDS buffer (the next stage waits in registers): 32 KiB (bf16) per workgroup,
   // three workgroups per CU, 32 KiB of loads in flight per workgroup.
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROWB = TNCfg<T>::ROWB;          // bytes per LDS tile row (128 columns)
   constexpr int CHUNKS = TNCfg<T>::CHUNKS;      // 16-B chunks per row
   constexpr int EPC = 16 / (int)sizeof(T);      // elements per chunk
@@ -321,8 +320,6 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(GemmTN<T> p) {
   constexpr int PER_THREAD = RS * CHUNKS / 256; // chunks per thread per operand
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave >> 1, wn = wave & 1;
-  const int split = blockIdx.x / p.tiles_nk;
-  const int t = blockIdx.x % p.tiles_nk;
   const int n0 = (t / p.tiles_k) * 128, k0 = (t % p.tiles_k) * 128;
   const int mbeg = split * p.rows_per_split;
   const int mend = min(p.M, mbeg + p.rows_per_split);
@@ -400,6 +397,76 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(GemmTN<T> p) {
         out[(size_t)part * p.part_size + (size_t)p.part_rows * p.K + (n - part * p.part_rows)] = red[tid] + red[tid + 128];
       }
     }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void gemm_tn_kernel(GemmTN<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  tn_body<T>(p, blockIdx.x / p.tiles_nk, blockIdx.x % p.tiles_nk, smem);
+}
+
+// grouped form: many weight-gradient products (all with plain row-major operands and the same reduction length M)
+// in ONE launch; block -> problem by binary search over the problems' first block.
+template <typename T>
+__global__ __launch_bounds__(256, 3) void gemm_tn_grouped_kernel(const eg_tn_problem* __restrict__ probs, int nprob,
+                                                                 int M, int splits, int rows_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int pi_s;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = nprob - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (probs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    pi_s = lo;
+  }
+  __syncthreads();
+  const eg_tn_problem q = probs[pi_s];
+  GemmTN<T> p;
+  p.dY = (const T*)q.dY; p.X = (const T*)q.X; p.partial = (float*)q.partial;
+  p.y.row_stride = q.ldy; p.y.group_stride = 0; p.y.rows_per_group = 0;
+  p.x.row_stride = q.ldx; p.x.group_stride = 0; p.x.rows_per_group = 0;
+  p.M = M; p.N = q.N; p.K = q.K; p.splits = splits; p.rows_per_split = rows_per_split;
+  p.tiles_k = (q.K + 127) / 128;
+  p.tiles_nk = p.tiles_k * ((q.N + 127) / 128);
+  p.x_tile_stride = 128;
+  p.part_rows = q.part_rows > 0 ? q.part_rows : q.N;
+  p.has_bias = q.has_bias;
+  p.part_size = (long long)p.part_rows * q.K + (q.has_bias ? p.part_rows : 0);
+  p.slab = (long long)(q.N / p.part_rows) * p.part_size;
+  const int local = blockIdx.x - q.blk0;
+  tn_body<T>(p, local / p.tiles_nk, local % p.tiles_nk, smem);
+}
+
+// table-driven form of the reduce below: entry e sums `splits` slabs of n floats into out
+__global__ __launch_bounds__(256) void reduce_table_kernel(const eg_reduce_entry* __restrict__ tab, int nent) {
+  __shared__ f32x4 red[32][8];
+  __shared__ int ei_s;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = nent - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (tab[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    ei_s = lo;
+  }
+  __syncthreads();
+  const eg_reduce_entry e = tab[ei_s];
+  const float* partial = (const float*)e.partial;
+  float* out = (float*)e.out;
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const long long i4 = ((long long)(blockIdx.x - e.blk0) * 8 + tx) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i4 + 4 <= e.n)
+    for (int k = ty; k < e.splits; k += 32) s += *(const f32x4*)(partial + (size_t)k * e.stride + i4);
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i4 + 4 <= e.n) {
+    f32x4 t = red[0][tx];
+#pragma unroll
+    for (int r = 1; r < 32; ++r) t += red[r][tx];
+    *(f32x4*)(out + i4) = t;
   }
 }
 
@@ -613,5 +680,29 @@ extern "C" int eg_colsum(const void* Y, eg_rowmap y, int M, int N, float* partia
   else
     return eg_fail("eg_colsum: bad dtype %d", dtype);
   EG_LAUNCH_CHECK("colsum");
+  return 0;
+}
+
+extern "C" int eg_gemm_tn_grouped(const eg_tn_problem* probs, int nprob, int total_blocks, int M, int splits, int dtype,
+                                  void* stream) {
+  EG_CHECK(probs && nprob > 0 && total_blocks > 0 && M > 0 && splits > 0, "eg_gemm_tn_grouped: bad arguments");
+  EG_CHECK(dtype == EG_F32 || dtype == EG_BF16, "eg_gemm_tn_grouped: bad dtype %d", dtype);
+  int rps = (M + splits - 1) / splits;
+  rps = (rps + 63) / 64 * 64;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel<bf16_t>, dim3(total_blocks), dim3(256), 2 * TNCfg<bf16_t>::STAGE_ROWS * TNCfg<bf16_t>::ROWB,
+                       s, probs, nprob, M, splits, rps);
+  else
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel<float>, dim3(total_blocks), dim3(256), 2 * TNCfg<float>::STAGE_ROWS * TNCfg<float>::ROWB,
+                       s, probs, nprob, M, splits, rps);
+  EG_LAUNCH_CHECK("gemm_tn_grouped");
+  return 0;
+}
+
+extern "C" int eg_reduce_table(const eg_reduce_entry* table, int nentries, int total_blocks, void* stream) {
+  EG_CHECK(table && nentries > 0 && total_blocks > 0, "eg_reduce_table: bad arguments");
+  hipLaunchKernelGGL(reduce_table_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, nentries);
+  EG_LAUNCH_CHECK("reduce_table");
   return 0;
 }

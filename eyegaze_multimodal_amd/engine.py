@@ -345,6 +345,61 @@ class Engine:
             else:
                 call("eg_reduce_partials", ptr(self.g["cspart"]), out_b, N, nblk, N, 0, self.stream)
 
+    # ------------------------------------------------------------------------------------------
+    # grouped weight gradients of the encoder: ONE launch for all 4*L products, ONE reduce launch
+    # ------------------------------------------------------------------------------------------
+    GROUP_SPLITS = 5
+    GROUP_MIN_ROWS = 4096   # below this the per-product launches (many splits) are the better shape
+
+    def _wgrad_group_plan(self):
+        if getattr(self, "_wg_plan", "unset") != "unset" and getattr(self, "_wg_key", None) == self.fp.grad.data_ptr():
+            return self._wg_plan
+        cfg, d, F, M, fp = self.cfg, self.cfg.d_model, self.cfg.d_ff, self.M, self.fp
+        self._wg_key = fp.grad.data_ptr()
+        self._wg_plan = None
+        if M < self.GROUP_MIN_ROWS:
+            return None
+        probs = []
+        for l in range(cfg.num_layers):
+            pre = f"encoder.layers.{l}."
+            probs += [([pre + "mha.out_proj"], f"dYo{l}", f"ctx{l}", d, d, d),
+                      ([pre + "mha.q_proj", pre + "mha.k_proj", pre + "mha.v_proj"], f"dqkv{l}", f"x{l}", 3 * d, d, 3 * d),
+                      ([pre + "ffn.linear2"], f"dYf{l}", f"hff{l}", d, F, d),
+                      ([pre + "ffn.linear1"], f"dh{l}", f"y1_{l}", F, d, F)]
+        for names, _, _, N, K, _ in probs:      # (weight, bias) pairs must sit back to back in the flat buffer
+            P = N // len(names)
+            base = fp.offsets[names[0] + ".weight"]
+            if not all(fp.offsets[n + ".weight"] == base + i * (P * K + P) and fp.offsets[n + ".bias"] == base + i * (P * K + P) + P * K
+                       for i, n in enumerate(names)):
+                return None
+        g = self.g
+        for l in range(cfg.num_layers):
+            g[f"dYo{l}"], g[f"dYf{l}"] = self._t(M, d), self._t(M, d)
+            g[f"dqkv{l}"], g[f"dh{l}"] = self._t(M, 3 * d), self._t(M, F)
+        splits = self.GROUP_SPLITS
+        total = sum(N * K + N for _, _, _, N, K, _ in probs)
+        g["wg_partial"] = self._t(splits * total, dtype=torch.float32)
+        tp = (L.TNProblem * len(probs))()
+        rt = (L.ReduceEntry * len(probs))()
+        blk, rblk, off = 0, 0, 0
+        for e, r, (names, dyn, xn, N, K, ldy) in zip(tp, rt, probs):
+            slab = N * K + N
+            base = ptr(g["wg_partial"]) + 4 * off
+            e.dY, e.X, e.partial = ptr(g[dyn]), ptr(self.a[xn]), base
+            e.ldy, e.ldx, e.N, e.K, e.part_rows, e.has_bias, e.blk0 = ldy, K, N, K, N // len(names), 1, blk
+            blk += ((N + 127) // 128) * ((K + 127) // 128) * splits
+            r.partial, r.out, r.n, r.stride, r.splits, r.blk0 = base, fp.g_ptr(names[0] + ".weight"), slab, slab, splits, rblk
+            rblk += (slab // 4 + 7) // 8
+            off += splits * slab
+        dev = lambda arr: torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        self._wg_plan = dict(tp=dev(tp), rt=dev(rt), n=len(probs), blocks=blk, rblocks=rblk, splits=splits)
+        return self._wg_plan
+
+    def _wgrad_group_launch(self):
+        pl = self._wg_plan
+        call("eg_gemm_tn_grouped", ptr(pl["tp"]), pl["n"], pl["blocks"], self.M, pl["splits"], self.dtype, self.stream)
+        call("eg_reduce_table", ptr(pl["rt"]), pl["n"], pl["rblocks"], self.stream)
+
     def ln_fwd(self, x, gname, y, stats):
         call("eg_layernorm_fwd", ptr(x), self.fp.p_ptr(gname + ".weight"), self.fp.p_ptr(gname + ".bias"), ptr(y),
              ptr(stats), self.M, self.cfg.d_model, self.dtype, self.stream)
@@ -554,22 +609,26 @@ class Engine:
         Lr = cfg.num_layers
         other = g["dzB"]
 
-        def attn_block_bwd(pre, l, x_in, dr, drm, kv_shift, site_attn, dx_out):
+        grouped = self._wgrad_group_plan() is not None
+
+        def attn_block_bwd(pre, l, x_in, dr, drm, kv_shift, site_attn, dx_out, dqkv, defer):
             """dr: grad of the pre-LN sum (residual path), drm: same, masked by the branch dropout."""
             names = [pre + n for n in ("q_proj", "k_proj", "v_proj")]
-            self.wgrad(ptr(drm), ptr(a[f"ctx{l}"]), 0, M, d, d, linear=[pre + "out_proj"])
+            if not defer:
+                self.wgrad(ptr(drm), ptr(a[f"ctx{l}"]), 0, M, d, d, linear=[pre + "out_proj"])
             self.gemm(ptr(drm), ptr(w[f"oT{l}"]), ptr(g["dctx"]), M, d, d)
-            call("eg_attention_bwd", ptr(a[f"qkv{l}"]), ptr(a[f"ctx{l}"]), ptr(g["dctx"]), ptr(a[f"lse{l}"]), ptr(g["dqkv"]),
+            call("eg_attention_bwd", ptr(a[f"qkv{l}"]), ptr(a[f"ctx{l}"]), ptr(g["dctx"]), ptr(a[f"lse{l}"]), ptr(dqkv),
                  NB, S, H, kv_shift, self.dtype, p, site_attn, self.st_ptr, st)
-            self.wgrad(ptr(g["dqkv"]), ptr(x_in), 0, M, 3 * d, d, linear=names)
-            self.gemm(ptr(g["dqkv"]), ptr(w[f"qkvT{l}"]), ptr(dx_out), M, d, 3 * d, residual=ptr(dr))
+            if not defer:
+                self.wgrad(ptr(dqkv), ptr(x_in), 0, M, 3 * d, d, linear=names)
+            self.gemm(ptr(dqkv), ptr(w[f"qkvT{l}"]), ptr(dx_out), M, d, 3 * d, residual=ptr(dr))
 
+        has_drop = p > 0
         if cfg.use_cross_attention:
             xs = _layer_sites(Lr)
-            has_drop = p > 0
             self.ln_bwd(dz, a["rx"], a["stx"], "cross_attn.norm", g["dr"], g["drm"] if has_drop else None, d1=(p, xs["drop1"]))
             drm = g["drm"] if has_drop else g["dr"]
-            attn_block_bwd("cross_attn.cross_attn.", "x", a["zn"], g["dr"], drm, B, xs["attn"], other)
+            attn_block_bwd("cross_attn.cross_attn.", "x", a["zn"], g["dr"], drm, B, xs["attn"], other, g["dqkv"], False)
             dz, other = other, dz
             seg("cross")
         # final encoder norm (A:328)
@@ -578,20 +637,37 @@ class Engine:
         seg("encoder.norm")
         for l in reversed(range(Lr)):
             pre, sites = f"encoder.layers.{l}.", _layer_sites(l)
-            has_drop = p > 0
-            self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", g["dr"], g["drm"] if has_drop else None,
-                        d1=(p, sites["ffn_b"]), d2=(p, sites["drop2"]))
-            drm = g["drm"] if has_drop else g["dr"]
-            self.wgrad(ptr(drm), ptr(a[f"hff{l}"]), 0, M, d, F, linear=[pre + "ffn.linear2"])
-            self.gemm(ptr(drm), ptr(w[f"w2T{l}"]), ptr(g["dh"]), M, F, d, gate=ptr(a[f"hff{l}"]), gate_scale=sc)
-            self.wgrad(ptr(g["dh"]), ptr(a[f"y1_{l}"]), 0, M, F, d, linear=[pre + "ffn.linear1"])
-            self.gemm(ptr(g["dh"]), ptr(w[f"w1T{l}"]), ptr(g["dy1"]), M, d, F, residual=ptr(g["dr"]))
-            self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", g["dr"], g["drm"] if has_drop else None,
-                        d1=(p, sites["drop1"]))
-            drm = g["drm"] if has_drop else g["dr"]
-            attn_block_bwd(pre + "mha.", l, a[f"x{l}"], g["dr"], drm, 0, sites["attn"], other)
+            # with the grouped weight-gradient launch every layer keeps its own dY operands until the end of backward
+            dYf = g[f"dYf{l}"] if grouped else (g["drm"] if has_drop else g["dr"])
+            dYo = g[f"dYo{l}"] if grouped else (g["drm"] if has_drop else g["dr"])
+            dh = g[f"dh{l}"] if grouped else g["dh"]
+            dqkv = g[f"dqkv{l}"] if grouped else g["dqkv"]
+            if has_drop:
+                self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", g["dr"], dYf, d1=(p, sites["ffn_b"]), d2=(p, sites["drop2"]))
+                dr = g["dr"]
+            else:
+                self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", dYf, None)
+                dr = dYf
+            if not grouped:
+                self.wgrad(ptr(dYf), ptr(a[f"hff{l}"]), 0, M, d, F, linear=[pre + "ffn.linear2"])
+            self.gemm(ptr(dYf), ptr(w[f"w2T{l}"]), ptr(dh), M, F, d, gate=ptr(a[f"hff{l}"]), gate_scale=sc)
+            if not grouped:
+                self.wgrad(ptr(dh), ptr(a[f"y1_{l}"]), 0, M, F, d, linear=[pre + "ffn.linear1"])
+            self.gemm(ptr(dh), ptr(w[f"w1T{l}"]), ptr(g["dy1"]), M, d, F, residual=ptr(dr))
+            if has_drop:
+                self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", g["dr"], dYo, d1=(p, sites["drop1"]))
+                dr = g["dr"]
+            else:
+                self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", dYo, None)
+                dr = dYo
+            attn_block_bwd(pre + "mha.", l, a[f"x{l}"], dr, dYo, 0, sites["attn"], other, dqkv, grouped)
             dz, other = other, dz
-            seg(f"layer{l}")
+            if not grouped:
+                seg(f"layer{l}")
+        if grouped:
+            self._wgrad_group_launch()
+            for l in reversed(range(Lr)):
+                seg(f"layer{l}")
         dseq = dz
         # positional table / cls token (A:120-126, D:1157)
         call("eg_batch_rowsum", ptr(dseq), fp.g_ptr("pos_embed.pos_embed.weight"), NB, S, d, S, self.dtype, st)

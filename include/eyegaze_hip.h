@@ -141,6 +141,22 @@ typedef struct eg_gemm_tn_desc {
   int32_t has_bias;      /* the layout of consecutive (weight, bias) parameters, so ONE eg_reduce_partials writes both */
 } eg_gemm_tn_desc;
 int eg_gemm_tn(const eg_gemm_tn_desc* d, void* stream);
+/* Grouped form: every weight-gradient product of the encoder in ONE launch (plain row-major operands, common
+ * reduction length M, common split count).  `probs` is a DEVICE array; problem i owns blocks [blk0, blk0 + tiles*splits)
+ * and writes its [splits, slab] partial slabs at `partial`.  eg_reduce_table sums many slab sets in one launch
+ * (n and stride must be multiples of 4 floats). */
+typedef struct eg_tn_problem {
+  uint64_t dY, X, partial;
+  int64_t ldy, ldx;
+  int32_t N, K, part_rows, has_bias, blk0, _pad;
+} eg_tn_problem;
+typedef struct eg_reduce_entry {
+  uint64_t partial, out;
+  int64_t n, stride;
+  int32_t splits, blk0;
+} eg_reduce_entry;
+int eg_gemm_tn_grouped(const eg_tn_problem* probs, int nprob, int total_blocks, int M, int splits, int dtype, void* stream);
+int eg_reduce_table(const eg_reduce_entry* table, int nentries, int total_blocks, void* stream);
 /* out[i] = (accumulate ? out[i] : 0) + sum_s partial[s*split_stride + i]; used for dW, db, LayerNorm dgamma/dbeta */
 int eg_reduce_partials(const float* partial, float* out, int64_t n, int splits, int64_t split_stride, int accumulate,
                        void* stream);

@@ -271,3 +271,29 @@ def test_cpu_tensors_are_refused():
     model = DualEEGTransformer(in_channels=8, max_len=256, use_spectrogram=False, use_ibs=False)
     with pytest.raises(L.EgError):
         model(torch.zeros(2, 8, 1024), torch.zeros(2, 8, 1024))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_grouped_weight_gradients_equal_per_product_path(dtype, monkeypatch):
+    """The one-launch grouped weight-gradient path (used at training batch sizes) produces the same gradients as the
+    per-product launches the small fixtures exercise."""
+    from eyegaze_multimodal_amd.engine import Engine
+    z, kw, cfg, sd, model = build("cfg3_xattn", dtype)
+    x1, x2, labels = t(z["randn/eeg1"]).to(DEV), t(z["randn/eeg2"]).to(DEV), t(z["labels"]).to(DEV)
+    one = torch.ones(1, device=DEV)
+    grads = []
+    for min_rows in (1 << 30, 0):
+        monkeypatch.setattr(Engine, "GROUP_MIN_ROWS", min_rows)
+        model._engines.clear()
+        eng = model.engine(x1.shape[0], x1.shape[2], x1.device)
+        eng.set_state(seed=5, lr=0.0, step=1)
+        eng.forward(x1, x2, labels, train=True)      # dropout on: the masked-gradient buffers are exercised too
+        eng.backward(gloss=one)
+        torch.cuda.synchronize()
+        assert (eng._wgrad_group_plan() is not None) == (min_rows == 0)
+        grads.append(model._flat.grad.clone())
+    ref, got = grads
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    # same products, different split counts: fp32 summation order only
+    assert err <= 2e-5 * float(ref.abs().max()) + 1e-7, err
