@@ -114,7 +114,8 @@ def main():
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     from eyegaze_multimodal_amd.graph import GraphedStep
-    graphed = None if args.eager else GraphedStep(eng, opt, train=True, reducer=reducer)
+    # N > 1: eager launches (same speed: the step is GPU-bound) keep the RCCL buckets out of graph capture
+    graphed = None if (args.eager or world > 1) else GraphedStep(eng, opt, train=True, reducer=reducer)
 
     def step(i, probe=None, eager=False):
         opt.begin_step(eng, seed=1000 + i, grad_scale=(reducer.grad_scale if reducer else 1.0))

@@ -146,7 +146,12 @@ def exported_symbols():
     return {n: hasattr(l, n) for n in list(SIGNATURES) + ["eg_abi_version", "eg_last_error"]}
 
 
+CALLS = 0  # number of C-ABI calls issued so far (graph.py uses it to skip empty capture segments)
+
+
 def call(name: str, *args):
+    global CALLS
+    CALLS += 1
     l = lib()
     rc = getattr(l, name)(*args)
     if rc != 0:

@@ -47,8 +47,8 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
   v[3] = pack2bf(b[2], b[3]);
   return __builtin_bit_cast(bf16x8, v);
 }
-__device__ __forceinline__ void stage_rows(char* img, const bf16_t* src, long long ld, int S, int SP, int lane) {
-  for (int id = lane; id < SP * 4; id += 64) {
+__device__ __forceinline__ void stage_rows(char* img, const bf16_t* src, long long ld, int S, int SP, int first, int step) {
+  for (int id = first; id < SP * 4; id += step) {
     const int row = id >> 2, c4 = id & 3;
     u32x4 v = {0u, 0u, 0u, 0u};
     if (row < S) v = *(const u32x4*)(src + (long long)row * ld + c4 * 8);
@@ -64,9 +64,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                                                        DropCfg dc, const eg_step_state* st) {
   constexpr int NKT = SP / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // two waves share one (window, head): they split the staging of V and take alternate query tiles
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, role = wave & 1;
   const int l15 = lane & 15, g = lane >> 4;
-  int pid = blockIdx.x * 4 + wave;
+  int pid = blockIdx.x * 2 + (wave >> 1);
   const bool valid = pid < NB * H;
   if (!valid) pid = NB * H - 1;
   const int b = pid / H, h = pid % H;
@@ -76,8 +77,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const bf16_t* qbase = qkv + (long long)b * S * ld + h * 32;
   const bf16_t* kbase = qkv + (long long)bk * S * ld + D + h * 32;
   const bf16_t* vbase = kbase + D;
-  char* vimg = smem + wave * (SP * 64);
-  stage_rows(vimg, vbase, ld, S, SP, lane);
+  char* vimg = smem + (wave >> 1) * (SP * 64);
+  stage_rows(vimg, vbase, ld, S, SP, lane + 64 * role, 128);
   const int nkt = (S + 15) >> 4;
   bf16x8 kf[NKT];
 #pragma unroll
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   uint32_t seed_lo = 0, seed_hi = 0;
   if (dc.thresh) { seed_lo = st->seed_lo; seed_hi = st->seed_hi; }
   __syncthreads();
-  for (int qt = 0; qt < nkt; ++qt) {
+  for (int qt = role; qt < nkt; qt += 2) {
     const int q = qt * 16 + l15;
     const bf16x8 qf = ld_frag_global(qbase + (long long)q * ld + g * 8, q < S);
     f32x4 s[NKT];
@@ -159,9 +160,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
   constexpr int NKT = SP / 16;
   constexpr int WB = 3 * SP * 64 + 2 * SP * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // two waves share one (window, head) and its LDS images: role 0 runs pass A (dQ) and the last k-tiles of pass B,
+  // role 1 the first k-tiles of pass B (dK, dV) -- twice the resident waves for the same LDS footprint
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, role = wave & 1;
   const int l15 = lane & 15, g = lane >> 4;
-  int pid = blockIdx.x * 4 + wave;
+  int pid = blockIdx.x * 2 + (wave >> 1);
   const bool valid = pid < NB * H;
   if (!valid) pid = NB * H - 1;
   const int b = pid / H, h = pid % H;
@@ -173,16 +176,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
   const bf16_t* vbase = kbase + D;
   const bf16_t* dobase = dctx + (long long)b * S * D + h * 32;
   const bf16_t* obase = ctx + (long long)b * S * D + h * 32;
-  char* base = smem + wave * WB;
+  char* base = smem + (wave >> 1) * WB;
   char* qimg = base;
   char* kimg = base + SP * 64;
   char* doimg = base + 2 * SP * 64;
   float* lsel = (float*)(base + 3 * SP * 64);
   float* dl = lsel + SP;
-  stage_rows(qimg, qbase, ld, S, SP, lane);
-  stage_rows(kimg, kbase, ld, S, SP, lane);
-  stage_rows(doimg, dobase, D, S, SP, lane);
-  for (int q = lane; q < SP; q += 64) {
+  stage_rows(qimg, qbase, ld, S, SP, lane + 64 * role, 128);
+  stage_rows(kimg, kbase, ld, S, SP, lane + 64 * role, 128);
+  stage_rows(doimg, dobase, D, S, SP, lane + 64 * role, 128);
+  for (int q = lane + 64 * role; q < SP; q += 128) {
     float l = 0.f, dsum = 0.f;
     if (q < S) {
       l = lse[((long long)b * H + h) * S + q];
@@ -212,7 +215,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
   __syncthreads();
 
   // ---- pass A: key rows / query lanes -> dQ ----
-  for (int qt = 0; qt < nkt; ++qt) {
+  const int kt_split = (3 * nkt + 2) / 5;   // role 1 takes k-tiles [0, kt_split), role 0 the rest after pass A
+  for (int qt = 0; qt < (role == 0 ? nkt : 0); ++qt) {
     const int q = qt * 16 + l15;
     const bf16x8 qf = ld_frag_lds_row(qimg, q, g);
     const bf16x8 dof = ld_frag_lds_row(doimg, q, g);
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
   }
 
   // ---- pass B: query rows / key lanes -> dK, dV ----
-  for (int kt = 0; kt < nkt; ++kt) {
+  for (int kt = (role == 0 ? kt_split : 0); kt < (role == 0 ? nkt : kt_split); ++kt) {
     const int key = kt * 16 + l15;
     f32x4 dk[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     f32x4 dv[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -444,16 +448,16 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(const float* __restri
 template <int SP>
 int launch_fwd(const void* qkv, void* ctx, float* lse, int NB, int S, int H, int kv_shift, DropCfg dc,
                const eg_step_state* st, hipStream_t s) {
-  const int nblk = (NB * H + 3) / 4;
-  hipLaunchKernelGGL(attn_fwd_kernel<SP>, dim3(nblk), dim3(256), 4 * SP * 64, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse,
+  const int nblk = (NB * H + 1) / 2;
+  hipLaunchKernelGGL(attn_fwd_kernel<SP>, dim3(nblk), dim3(256), 2 * SP * 64, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse,
                      NB, S, H, kv_shift, dc, st);
   return 0;
 }
 template <int SP>
 int launch_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int NB, int S, int H,
                int kv_shift, DropCfg dc, const eg_step_state* st, hipStream_t s) {
-  const int nblk = (NB * H + 3) / 4;
-  constexpr int lds = 4 * (3 * SP * 64 + 2 * SP * 4);
+  const int nblk = (NB * H + 1) / 2;
+  constexpr int lds = 2 * (3 * SP * 64 + 2 * SP * 4);
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)attn_bwd_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -12,6 +12,8 @@ from typing import List, Optional, Tuple
 
 import torch
 
+from . import _lib
+
 
 class GraphedStep:
     def __init__(self, eng, opt, train: bool = True, reducer=None):
@@ -21,7 +23,7 @@ class GraphedStep:
         self.x2 = torch.zeros(eng.B, eng.C, eng.T, device=dev)
         self.labels = torch.zeros(eng.B, dtype=torch.int64, device=dev)
         self.one = torch.ones(1, device=dev)
-        self.graphs: List[Tuple[str, torch.cuda.CUDAGraph]] = []
+        self.graphs: List[Tuple[List[str], torch.cuda.CUDAGraph]] = []  # (segments finished by this graph, graph)
         self.captured = False
 
     def _capture(self):
@@ -30,30 +32,29 @@ class GraphedStep:
         side.wait_stream(torch.cuda.current_stream(eng.device))
         graphs = self.graphs
         with torch.cuda.stream(side):
-            cur = {"g": torch.cuda.CUDAGraph(), "name": "forward"}
+            cur = {"g": torch.cuda.CUDAGraph(), "names": [], "calls": _lib.CALLS}
             cur["g"].capture_begin()
 
-            def cut(next_name):
+            def cut(reopen=True):
                 cur["g"].capture_end()
-                graphs.append((cur["name"], cur["g"]))
-                if next_name is not None:
-                    cur["g"], cur["name"] = torch.cuda.CUDAGraph(), next_name
+                graphs.append((cur["names"], cur["g"]))
+                if reopen:
+                    cur["g"], cur["names"], cur["calls"] = torch.cuda.CUDAGraph(), [], _lib.CALLS
                     cur["g"].capture_begin()
 
             eng.forward(self.x1, self.x2, self.labels, train=self.train)
-            cut("bwd")
-            order = []
 
             def seg(name):
-                order.append(name)
-                cur["name"] = name        # the graph just captured produced segment `name`
-                cut("bwd")
+                if _lib.CALLS == cur["calls"] and graphs:   # nothing launched since the last cut: same graph finished it
+                    graphs[-1][0].append(name)
+                    return
+                cur["names"].append(name)
+                cut()
 
             eng.backward(gloss=self.one, on_segment=seg)
-            # the last cut() opened an empty capture for the optimiser: fill it
-            cur["name"] = "optimizer"
+            cur["names"].append("optimizer")
             opt.step(eng)
-            cut(None)
+            cut(reopen=False)
         torch.cuda.current_stream(eng.device).wait_stream(side)
         self.captured = True
 
@@ -65,9 +66,11 @@ class GraphedStep:
         if not self.captured:
             self._capture()
         red = self.reducer
-        for name, g in self.graphs:
-            if name == "optimizer" and red is not None:
+        for names, g in self.graphs:
+            if red is not None and "optimizer" in names:
                 red.finish()
             g.replay()
-            if red is not None and name not in ("forward", "optimizer"):
-                red.on_segment(name)
+            if red is not None:
+                for name in names:
+                    if name != "optimizer":
+                        red.on_segment(name)
