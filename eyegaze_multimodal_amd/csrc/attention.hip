@@ -121,15 +121,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (g == 0 && q < S && valid) lse[((long long)b * H + h) * S + q] = mx + __logf(sum);
-    const uint32_t rowidx = (uint32_t)((b * H + h) * S + q) * (uint32_t)S;
+    const uint32_t rowidx = (uint32_t)((b * H + h) * S + q) * (uint32_t)((S + 1) & ~1);  // even row pitch: aligned pairs
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+      float pv[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float p = s[kt][r] * inv;
-        if (dc.thresh) p = eg_dropout(p, dc, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g + r));
-        s[kt][r] = p;
-      }
+      for (int r = 0; r < 4; ++r) pv[r] = s[kt][r] * inv;
+      eg_dropout_run<4>(pv, dc, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[kt][r] = pv[r];
+    }
     f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int kp = 0; kp < NKT / 2; ++kp) {
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     const bf16x8 qf = ld_frag_lds_row(qimg, q, g);
     const bf16x8 dof = ld_frag_lds_row(doimg, q, g);
     const float lq = lsel[q], dq = dl[q];
-    const uint32_t rowidx = (headidx + (uint32_t)q) * (uint32_t)S;
+    const uint32_t Sp2 = (uint32_t)((S + 1) & ~1);
+    const uint32_t rowidx = (headidx + (uint32_t)q) * Sp2;
     f32x4 ds[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -230,13 +232,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         const f32x4 sT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf, z, 0, 0, 0);
         const f32x4 dpT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kt], dof, z, 0, 0, 0);
+        float dpv[4] = {dpT[0], dpT[1], dpT[2], dpT[3]};
+        eg_dropout_run<4>(dpv, dc, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + 4 * g + r;
           const float p = key < S ? __expf(sT[r] * kScale - lq) : 0.f;
-          float dp = dpT[r];
-          if (dc.thresh) dp = eg_dropout(dp, dc, seed_lo, seed_hi, rowidx + (uint32_t)key);
-          ds[kt][r] = p * (dp - dq);
+          ds[kt][r] = p * (dpv[r] - dq);
         }
       }
     }
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
               const int qq = qt * 16 + 4 * g + r;
               const float p = (key < S && qq < S) ? __expf(s[r] * kScale - l4[r]) : 0.f;
               float m = 1.0f;
-              if (dc.thresh) m = eg_dropout(1.0f, dc, seed_lo, seed_hi, (headidx + (uint32_t)qq) * (uint32_t)S + (uint32_t)key);
+              if (dc.thresh) m = eg_dropout(1.0f, dc, seed_lo, seed_hi, (headidx + (uint32_t)qq) * (uint32_t)((S + 1) & ~1) + (uint32_t)key);
               pd2[h2][r] = p * m;
               ds2[h2][r] = p * (dp[r] * m - d4[r]);
             }
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
   const float inv = 1.0f / sum;
   uint32_t seed_lo = 0, seed_hi = 0;
   if (dc.thresh) { seed_lo = st->seed_lo; seed_hi = st->seed_hi; }
-  const uint32_t rowidx = (uint32_t)((b * H + h) * S + q) * (uint32_t)S;
+  const uint32_t rowidx = (uint32_t)((b * H + h) * S + q) * (uint32_t)((S + 1) & ~1);
   for (int k = 0; k < S; ++k) {
     float p = expf(dot32(qv, Kl + k * 32) * kScale - mx) * inv;
     if (dc.thresh) p = eg_dropout(p, dc, seed_lo, seed_hi, rowidx + (uint32_t)k);
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(const float* __restri
     for (int k = 0; k < S; ++k) {
       const float p = expf(dot32(Ql + t * 32, Kl + k * 32) * kScale - lsel[t]);
       float dp = dot32(Dl + t * 32, Vl + k * 32);
-      if (dc.thresh) dp = eg_dropout(dp, dc, seed_lo, seed_hi, (headidx + (uint32_t)t) * (uint32_t)S + (uint32_t)k);
+      if (dc.thresh) dp = eg_dropout(dp, dc, seed_lo, seed_hi, (headidx + (uint32_t)t) * (uint32_t)((S + 1) & ~1) + (uint32_t)k);
       const float ds = p * (dp - dl[t]);
 #pragma unroll
       for (int d = 0; d < 32; ++d) acc[d] = fmaf(ds, Kl[k * 32 + d], acc[d]);
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(const float* __restri
       const float p = expf(dot32(Ql + q * 32, Kl + t * 32) * kScale - lsel[q]);
       const float dpr = dot32(Dl + q * 32, Vl + t * 32);
       float m = 1.0f;
-      if (dc.thresh) m = eg_dropout(1.0f, dc, seed_lo, seed_hi, (headidx + (uint32_t)q) * (uint32_t)S + (uint32_t)t);
+      if (dc.thresh) m = eg_dropout(1.0f, dc, seed_lo, seed_hi, (headidx + (uint32_t)q) * (uint32_t)((S + 1) & ~1) + (uint32_t)t);
       const float pd = p * m, ds = p * (dpr * m - dl[q]);
 #pragma unroll
       for (int d = 0; d < 32; ++d) {
@@ -476,7 +478,7 @@ static int attn_check(const char* who, int NB, int S, int H, int kv_shift, int d
   EG_CHECK(kv_shift >= 0 && kv_shift < NB, "%s: kv_shift=%d out of range", who, kv_shift);
   EG_CHECK(dtype == EG_BF16 || dtype == EG_F32, "%s: bad dtype %d", who, dtype);
   EG_CHECK(p >= 0.f && p < 1.f && (p == 0.f || st), "%s: dropout p=%f needs a step state", who, (double)p);
-  EG_CHECK((long long)NB * H * S * S < (1ll << 32), "%s: NB*H*S*S exceeds the 32-bit dropout index", who);
+  EG_CHECK((long long)NB * H * S * (S + 1) < (1ll << 32), "%s: NB*H*S*S exceeds the 32-bit dropout index", who);
   return 0;
 }
 

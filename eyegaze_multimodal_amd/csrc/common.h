@@ -100,8 +100,10 @@ __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// counter-based dropout mask.  One 32-bit hash per element; identical in forward and backward
-// because it depends only on (seed, site, element index).  keep <=> low 24 bits >= p * 2^24.
+// counter-based dropout mask, identical in forward and backward because it depends only on
+// (seed, site, element index).  One 32-bit hash serves TWO consecutive elements (its 16-bit halves):
+// keep <=> half >= round(p * 2^16).  32-bit integer multiplies are quarter rate on CDNA, so halving the
+// hash count matters (the hash is ~60 % of the attention backward's VALU time).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t eg_hash(uint32_t seed_lo, uint32_t seed_hi, uint32_t site, uint32_t idx) {
   uint32_t x = idx ^ (site * 0x9E3779B9u) ^ seed_lo;
@@ -112,18 +114,32 @@ __device__ __forceinline__ uint32_t eg_hash(uint32_t seed_lo, uint32_t seed_hi, 
   return x;
 }
 struct DropCfg {
-  uint32_t thresh;  // round(p * 2^24); 0 = disabled
+  uint32_t thresh;  // round(p * 2^16); 0 = disabled
   float scale;      // 1/(1-p)
   uint32_t site;
 };
+// single element (index idx): uses half (idx & 1) of the pair hash
 __device__ __forceinline__ float eg_dropout(float v, const DropCfg& d, uint32_t seed_lo, uint32_t seed_hi, uint32_t idx) {
   if (d.thresh == 0) return v;
-  uint32_t h = eg_hash(seed_lo, seed_hi, d.site, idx) & 0xFFFFFFu;
-  return h >= d.thresh ? v * d.scale : 0.0f;
+  const uint32_t h = eg_hash(seed_lo, seed_hi, d.site, idx >> 1);
+  const uint32_t half = (idx & 1u) ? (h >> 16) : (h & 0xFFFFu);
+  return half >= d.thresh ? v * d.scale : 0.0f;
+}
+// N consecutive elements starting at an EVEN index: N/2 hashes
+template <int N>
+__device__ __forceinline__ void eg_dropout_run(float (&v)[N], const DropCfg& d, uint32_t seed_lo, uint32_t seed_hi,
+                                               uint32_t idx0) {
+  if (d.thresh == 0) return;
+#pragma unroll
+  for (int j = 0; j < N; j += 2) {
+    const uint32_t h = eg_hash(seed_lo, seed_hi, d.site, (idx0 + j) >> 1);
+    v[j] = (h & 0xFFFFu) >= d.thresh ? v[j] * d.scale : 0.0f;
+    v[j + 1] = (h >> 16) >= d.thresh ? v[j + 1] * d.scale : 0.0f;
+  }
 }
 static inline DropCfg make_drop(float p, uint32_t site) {
   DropCfg d;
-  d.thresh = p > 0.f ? (uint32_t)(p * 16777216.0f + 0.5f) : 0u;
+  d.thresh = p > 0.f ? (uint32_t)(p * 65536.0f + 0.5f) : 0u;
   d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   d.site = site;
   return d;

@@ -181,12 +181,9 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmNT<T> p) {
           for (int j = 0; j < 8; ++j) v[j] = gv[j] > 0.f ? v[j] * p.gate_scale : 0.f;
         }
         if (p.d1.thresh | p.d2.thresh) {
-          const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            v[j] = eg_dropout(v[j], p.d1, seed_lo, seed_hi, idx + j);
-            v[j] = eg_dropout(v[j], p.d2, seed_lo, seed_hi, idx + j);
-          }
+          const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;  // even: N % 8 == 0, n % 8 == 0
+          eg_dropout_run<8>(v, p.d1, seed_lo, seed_hi, idx);
+          eg_dropout_run<8>(v, p.d2, seed_lo, seed_hi, idx);
         }
         if (p.out_pre) store8(p.out_pre + row_off(p.pm, m) + n, v);
         if (p.residual) {

@@ -111,11 +111,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         if (dx_drop) {
           if (drop) {
             const uint32_t idx = (uint32_t)row * (uint32_t)D + (uint32_t)(c * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              o[e] = eg_dropout(o[e], d1, seed_lo, seed_hi, idx + e);
-              o[e] = eg_dropout(o[e], d2, seed_lo, seed_hi, idx + e);
-            }
+            eg_dropout_run<4>(o, d1, seed_lo, seed_hi, idx);
+            eg_dropout_run<4>(o, d2, seed_lo, seed_hi, idx);
           }
           store4(dx_drop + (size_t)row * D + c * 4, o);
         }
@@ -225,11 +222,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd256_kernel(const T* __restri
       if (dx_drop) {
         if (drop) {
           const uint32_t idx = (uint32_t)row * 256u + (uint32_t)(l * 8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            o[e] = eg_dropout(o[e], d1, seed_lo, seed_hi, idx + e);
-            o[e] = eg_dropout(o[e], d2, seed_lo, seed_hi, idx + e);
-          }
+          eg_dropout_run<8>(o, d1, seed_lo, seed_hi, idx);
+          eg_dropout_run<8>(o, d2, seed_lo, seed_hi, idx);
         }
         store8(dx_drop + (size_t)row * 256 + l * 8, o);
       }
