@@ -119,6 +119,22 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmNT<T> p) {
     ra[i] = *(const u32x4*)(ap[i]);
     rw[i] = *(const u32x4*)(wp[i]);
   }
+  // the epilogue's residual (or gate) rows are requested early so their latency hides under the K loop / under the
+  // other half's epilogue: 4 x 16 B per thread and half (16-bit types only)
+  constexpr bool kPre = sizeof(T) == 2;
+  const T* const eop = p.residual ? p.residual : p.gate;
+  const RowMap& emap = p.residual ? p.r : p.c;
+  const int en = n0 + (tid & 15) * 8;
+  u32x4 pre[4];
+  auto prefetch_epi = [&](int half) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + half * 64 + (tid >> 4) + 16 * i;
+      pre[i] = (u32x4){0u, 0u, 0u, 0u};
+      if (kPre && eop && m < p.M && en < p.N) pre[i] = *(const u32x4*)(eop + row_off(emap, m) + en);
+    }
+  };
+  prefetch_epi(0);
   for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -163,6 +179,10 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmNT<T> p) {
           *(f32x4*)(ct + (mi * 16 + l15) * CT_PITCH + wn * 64 + ni * 16 + 4 * g) = acc[ni][mi];
     }
     __syncthreads();
+    u32x4 cur[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur[i] = pre[i];
+    if (half == 0) prefetch_epi(1);
     if (n < p.N) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -176,7 +196,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmNT<T> p) {
         const long long coff = row_off(p.c, m) + n;
         if (p.gate) {
           float gv[8];
-          load8(p.gate + coff, gv);
+          if (kPre && !p.residual) load8((const T*)&cur[i], gv);
+          else load8(p.gate + coff, gv);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = gv[j] > 0.f ? v[j] * p.gate_scale : 0.f;
         }
@@ -188,7 +209,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmNT<T> p) {
         if (p.out_pre) store8(p.out_pre + row_off(p.pm, m) + n, v);
         if (p.residual) {
           float rv[8];
-          load8(p.residual + row_off(p.r, m) + n, rv);
+          if (kPre) load8((const T*)&cur[i], rv);
+          else load8(p.residual + row_off(p.r, m) + n, rv);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += rv[j];
         }
@@ -499,14 +521,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // conv weight gradient: partial [splits][N][Kp] in tap-major order (k = tap*Cp + c) -> dW [N][Cin][k] (parameter layout)
 __global__ void unpack_conv_wgrad_kernel(const float* __restrict__ partial, float* __restrict__ dW, int splits, int N,
                                          int Cin, int k, int Cp, int Kp) {
+  // one thread per element of the tap-major slab (coalesced over the splits); the 4-B store is the scattered side
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)N * Cin * k) return;
-  const int tap = (int)(i % k);
-  const int c = (int)((i / k) % Cin);
-  const int n = (int)(i / ((long long)k * Cin));
+  if (i >= (long long)N * Kp) return;
+  const int n = (int)(i / Kp), kk = (int)(i % Kp);
+  const int tap = kk / Cp, c = kk % Cp;
+  if (tap >= k || c >= Cin) return;
   float s = 0.f;
-  for (int sp = 0; sp < splits; ++sp) s += partial[((size_t)sp * N + n) * Kp + tap * Cp + c];
-  dW[i] = s;
+  for (int sp = 0; sp < splits; ++sp) s += partial[(size_t)sp * N * Kp + i];
+  dW[((size_t)n * Cin + c) * k + tap] = s;
 }
 
 // column sums of a [M, N] matrix: block b sums rows [b*rpb, (b+1)*rpb) -> partial[b, N]
@@ -656,7 +679,7 @@ extern "C" int eg_unpack_conv_wgrad(const float* partial, float* dW, int splits,
                                     void* stream) {
   EG_CHECK(partial && dW && splits > 0 && N > 0 && Cin > 0 && k > 0 && Cp >= Cin && Kp >= k * Cp,
            "eg_unpack_conv_wgrad: bad arguments");
-  const long long n = (long long)N * Cin * k;
+  const long long n = (long long)N * Kp;
   hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      partial, dW, splits, N, Cin, k, Cp, Kp);
   EG_LAUNCH_CHECK("unpack_conv_wgrad");
