@@ -422,7 +422,8 @@ __device__ __forceinline__ void tn_body(const GemmTN<T>& p, const int split, con
 template <typename T>
 __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(GemmTN<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  tn_body<T>(p, blockIdx.x / p.tiles_nk, blockIdx.x % p.tiles_nk, smem);
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  tn_body<T>(p, bid / p.tiles_nk, bid % p.tiles_nk, smem);
 }
 
 // grouped form: many weight-gradient products (all with plain row-major operands and the same reduction length M)
@@ -432,11 +433,13 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_grouped_kernel(const eg_tn_pro
                                                                  int M, int splits, int rows_per_split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int pi_s;
+  // XCD-aware order: the tiles of one (problem, row range) read the same dY / X rows, so they must share an L2
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   if (threadIdx.x == 0) {
     int lo = 0, hi = nprob - 1;
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
-      if (probs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+      if (probs[mid].blk0 <= bid) lo = mid; else hi = mid - 1;
     }
     pi_s = lo;
   }
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_grouped_kernel(const eg_tn_pro
   p.has_bias = q.has_bias;
   p.part_size = (long long)p.part_rows * q.K + (q.has_bias ? p.part_rows : 0);
   p.slab = (long long)(q.N / p.part_rows) * p.part_size;
-  const int local = blockIdx.x - q.blk0;
+  const int local = bid - q.blk0;
   tn_body<T>(p, local / p.tiles_nk, local % p.tiles_nk, smem);
 }
 
