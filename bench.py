@@ -72,7 +72,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="windows pairs per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
+    ap.add_argument("--graph", action="store_true", help="replay captured hipGraphs instead of eager launches")
+    ap.add_argument("--eager", action="store_true", help="(default) accepted for compatibility")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
     args = ap.parse_args()
@@ -111,47 +112,44 @@ def main():
     ranges = bucket_ranges(fp.names, fp.offsets, fp.total, model.cfg.num_layers, model.cfg.use_cross_attention)
     reducer = GradAllReducer(fp.grad, ranges) if world > 1 else None
     one = torch.ones(1, device=dev)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     from eyegaze_multimodal_amd.graph import GraphedStep
-    # N > 1: eager launches (same speed: the step is GPU-bound) keep the RCCL buckets out of graph capture
-    graphed = None if (args.eager or world > 1) else GraphedStep(eng, opt, train=True, reducer=reducer)
+    # default: every kernel is launched eagerly so that HIP events can bracket the dominant kernel's launches INSIDE the
+    # timed region (events cannot be recorded inside a replayed graph).  The step is GPU-bound, so eager == graph speed;
+    # --graph replays captured hipGraphs instead (then the probe runs right after the timed region).
+    graphed = GraphedStep(eng, opt, train=True, reducer=reducer) if (args.graph and world == 1) else None
 
-    def step(i, probe=None, eager=False):
+    def step(i, probe=False, eager=False):
         opt.begin_step(eng, seed=1000 + i, grad_scale=(reducer.grad_scale if reducer else 1.0))
         if graphed is not None and not eager:
             graphed.run(x1, x2, labels)
             return
-        eng.probes = {"conv1_fwd": probe} if probe else {}
+        eng.probe_all = probes if probe else None
         eng.forward(x1, x2, labels, train=True)
         eng.backward(gloss=one, on_segment=(reducer.on_segment if reducer else None))
+        eng.probe_all = None
         if reducer:
             reducer.finish()
         opt.step(eng)
 
+    probes = []
     step(0, eager=True)  # first step eagerly: lazy workspace allocation and one-time kernel attributes
     for i in range(args.warmup):
         step(i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    probe_ms = []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i, probe=evs[i])  # HIP events on the launch stream; read after the timed region
+        step(args.warmup + i, probe=(graphed is None and i < 8))  # events on the launch stream, read after the region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if graphed is not None:
-        # HIP events cannot be recorded inside a replayed graph: time the probed launch live right after the timed
-        # region (same buffers, same stream), eager, events on the launch stream
+        for i in range(4):
+            step(args.warmup + args.steps + i, probe=True, eager=True)
         torch.cuda.synchronize()
-        for a, b in evs[:8]:
-            step(args.warmup + args.steps, probe=(a, b), eager=True)
-        torch.cuda.synchronize()
-        evs = evs[:8]
-    probe_ms = [a.elapsed_time(b) for a, b in evs]
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -162,12 +160,18 @@ def main():
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
-        # dominant-kernel roofline: conv-1 as an MFMA GEMM, M = 2B*T2 rows, N = d, K = 25*d  
-        M, N, K = eng.NB * eng.T2, model.cfg.d_model, eng.k * model.cfg.d_model
-        flops = 2.0 * M * N * K
-        kms = sum(probe_ms) / len(probe_ms)
+        # dominant kernel = gemm_nt_kernel (~45 % of the step's GPU time, profiles/): every forward product (strided convs,
+        # q/k/v/out, FFN, heads) and every backward-data product.  achieved = algorithmic FLOPs per launch (2*M*N*K,
+        # averaged over the kernel's launches of a step) / its average launch duration from the HIP events above.
+        n_launch = len(probes)
+        kms = sum(a.elapsed_time(b) for a, b, _ in probes) / max(n_launch, 1)
+        flops = sum(f for _, _, f in probes) / max(n_launch, 1)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         achieved = flops / (kms * 1e-3) / 1e12
+        traffic = None
+        pmc = REPO / "profiles" / "r01_pmc_gemm_nt.json"
+        if pmc.exists() and args.workload == "cfg2" and B == 256 and args.dtype == "bf16":
+            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
         out = {
             "metric": "train samples/sec (gaze+EEG windows)", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
@@ -176,10 +180,10 @@ def main():
                        "seq_len": eng.S, "d_model": model.cfg.d_model, "layers": model.cfg.num_layers,
                        "step": "fwd(train,dropout)+bwd+allreduce+clip+AdamW", "parallelism": f"dp{world}",
                        "final_loss": round(loss, 5)},
-            "roofline": {"kernel": "gemm_nt_kernel<bf16> (conv-1 forward: strided Conv1d as MFMA GEMM)" if args.dtype == "bf16"
-                         else "gemm_nt_kernel<f32>", "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-                         "launch_ms": round(kms, 4), "algorithmic_flops_per_launch": flops},
+            "roofline": {"kernel": f"gemm_nt_kernel<{args.dtype}> (all {n_launch // (min(8, args.steps) if graphed is None else 4)} launches of a step)",
+                         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic, "launch_ms": round(kms, 5),
+                         "algorithmic_flops_per_launch": round(flops)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(kw, C, T)

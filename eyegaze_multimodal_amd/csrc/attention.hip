@@ -290,33 +290,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
             const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dorow, vfr, z, 0, 0, 0);
             const f32x4 l4 = *(const f32x4*)(lsel + qt * 16 + 4 * g);
             const f32x4 d4 = *(const f32x4*)(dl + qt * 16 + 4 * g);
-            // dropout masks: element (qq, key) uses half (key & 1) of hash((qq*Sp2 + key) >> 1); lanes key and key^1
-            // share that hash, so each computes two of the four rows and fetches the other two from its neighbour
-            float m4[4] = {1.f, 1.f, 1.f, 1.f};
-            if (dc.thresh) {
-              const uint32_t Sp2b = (uint32_t)((S + 1) & ~1);
-              uint32_t hh[4];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                hh[r] = 0u;
-                if ((r & 1) == (l15 & 1)) {
-                  const uint32_t qq = (uint32_t)(qt * 16 + 4 * g + r);
-                  hh[r] = eg_hash(seed_lo, seed_hi, dc.site, ((headidx + qq) * Sp2b + (uint32_t)key) >> 1);
-                }
-              }
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const uint32_t other = (uint32_t)__shfl_xor((int)hh[r], 1, 64);
-                const uint32_t hv = ((r & 1) == (l15 & 1)) ? hh[r] : other;
-                const uint32_t half = (key & 1) ? (hv >> 16) : (hv & 0xFFFFu);
-                m4[r] = half >= dc.thresh ? dc.scale : 0.f;
-              }
-            }
+            const uint32_t Sp2b = (uint32_t)((S + 1) & ~1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int qq = qt * 16 + 4 * g + r;
               const float p = (key < S && qq < S) ? __expf(s[r] * kScale - l4[r]) : 0.f;
-              const float m = m4[r];
+              float m = 1.0f;
+              if (dc.thresh) m = eg_dropout(1.0f, dc, seed_lo, seed_hi, (headidx + (uint32_t)qq) * Sp2b + (uint32_t)key);
               pd2[h2][r] = p * m;
               ds2[h2][r] = p * (dp[r] * m - d4[r]);
             }

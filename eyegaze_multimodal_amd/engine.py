@@ -127,7 +127,8 @@ class Engine:
         self.M = self.NB * self.S
         self.fp: FlatParams = model._flat
         self.stream = 0
-        self.probes = {}   # tag -> (start_event, end_event) recorded around that launch (bench.py roofline probe)
+        self.probes = {}   # tag -> (start_event, end_event) recorded around that launch
+        self.probe_all = None  # list of (start, end, flops) for every gemm_nt launch when bench.py enables it
         self._alloc()
         self.packed_version = -1
         self._recording = False
@@ -268,6 +269,9 @@ class Engine:
     def gemm(self, A, W, Cout, M, N, K, *, a=None, c=None, r=None, p=None, ldw=None, bias=0, residual=0, gate=0,
              out_pre=0, act=0, drop1=(0.0, 0), drop2=(0.0, 0), gate_scale=1.0, tag=None, seg=(0, 0)):
         probe = self.probes.get(tag) if tag else None
+        if self.probe_all is not None:      # bench.py: HIP events around EVERY gemm_nt launch of the timed region
+            probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.probe_all.append((probe[0], probe[1], 2.0 * M * N * K))
         if probe:
             probe[0].record(torch.cuda.current_stream(self.device))
         self._gemm(A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale, seg)
