@@ -240,8 +240,18 @@ __global__ __launch_bounds__(256) void batch_rowsum_kernel(const T* __restrict__
   __shared__ float red[4][64];
   const int s = blockIdx.x, n = blockIdx.y * 64 + (threadIdx.x & 63), bl = threadIdx.x >> 6;
   float a = 0.f;
-  if (n < D)
-    for (int b = bl; b < NB; b += 4) a += Elem<T>::ld(dseq + ((size_t)b * S + s) * D + n);
+  if (n < D) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four independent loads in flight per thread
+    int b = bl;
+    for (; b + 12 < NB; b += 16) {
+      a0 += Elem<T>::ld(dseq + ((size_t)b * S + s) * D + n);
+      a1 += Elem<T>::ld(dseq + ((size_t)(b + 4) * S + s) * D + n);
+      a2 += Elem<T>::ld(dseq + ((size_t)(b + 8) * S + s) * D + n);
+      a3 += Elem<T>::ld(dseq + ((size_t)(b + 12) * S + s) * D + n);
+    }
+    for (; b < NB; b += 4) a0 += Elem<T>::ld(dseq + ((size_t)b * S + s) * D + n);
+    a = (a0 + a1) + (a2 + a3);
+  }
   red[bl][threadIdx.x & 63] = a;
   __syncthreads();
   if (bl == 0 && n < D) {

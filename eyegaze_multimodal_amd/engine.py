@@ -383,8 +383,13 @@ class Engine:
         splits = self.GROUP_SPLITS
         total = sum(N * K + N for _, _, _, N, K, _ in probs)
         g["wg_partial"] = self._t(splits * total, dtype=torch.float32)
+        ln_names = [f"encoder.layers.{l}.{n}" for l in range(cfg.num_layers) for n in ("ln1", "ln2")]
+        if not all(fp.offsets[n + ".bias"] == fp.offsets[n + ".weight"] + d for n in ln_names):
+            return None
+        g["lnpart_all"] = self._t(len(ln_names) * self.LN_BLOCKS * 2 * d, dtype=torch.float32)
+        self._ln_slot = {n: i for i, n in enumerate(ln_names)}
         tp = (L.TNProblem * len(probs))()
-        rt = (L.ReduceEntry * len(probs))()
+        rt = (L.ReduceEntry * (len(probs) + len(ln_names)))()
         blk, rblk, off = 0, 0, 0
         for e, r, (names, dyn, xn, N, K, ldy) in zip(tp, rt, probs):
             slab = N * K + N
@@ -395,25 +400,36 @@ class Engine:
             r.partial, r.out, r.n, r.stride, r.splits, r.blk0 = base, fp.g_ptr(names[0] + ".weight"), slab, slab, splits, rblk
             rblk += (slab // 4 + 7) // 8
             off += splits * slab
+        for i, n in enumerate(ln_names):   # deferred LayerNorm gain / bias partials ride in the same reduce launch
+            r = rt[len(probs) + i]
+            r.partial, r.out = ptr(g["lnpart_all"]) + 4 * i * self.LN_BLOCKS * 2 * d, fp.g_ptr(n + ".weight")
+            r.n, r.stride, r.splits, r.blk0 = 2 * d, 2 * d, self.LN_BLOCKS, rblk
+            rblk += (2 * d // 4 + 7) // 8
         dev = lambda arr: torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-        self._wg_plan = dict(tp=dev(tp), rt=dev(rt), n=len(probs), blocks=blk, rblocks=rblk, splits=splits)
+        self._wg_plan = dict(tp=dev(tp), rt=dev(rt), n=len(probs), nr=len(probs) + len(ln_names), blocks=blk, rblocks=rblk,
+                             splits=splits)
         return self._wg_plan
 
     def _wgrad_group_launch(self):
         pl = self._wg_plan
         call("eg_gemm_tn_grouped", ptr(pl["tp"]), pl["n"], pl["blocks"], self.M, pl["splits"], self.dtype, self.stream)
-        call("eg_reduce_table", ptr(pl["rt"]), pl["n"], pl["rblocks"], self.stream)
+        call("eg_reduce_table", ptr(pl["rt"]), pl["nr"], pl["rblocks"], self.stream)
 
     def ln_fwd(self, x, gname, y, stats):
         call("eg_layernorm_fwd", ptr(x), self.fp.p_ptr(gname + ".weight"), self.fp.p_ptr(gname + ".bias"), ptr(y),
              ptr(stats), self.M, self.cfg.d_model, self.dtype, self.stream)
 
-    def ln_bwd(self, dy, x, stats, gname, dx, dx_drop=None, d1=(0.0, 0), d2=(0.0, 0)):
+    LN_BLOCKS = 512
+
+    def ln_bwd(self, dy, x, stats, gname, dx, dx_drop=None, d1=(0.0, 0), d2=(0.0, 0), slot=None):
+        """slot: index into the deferred gain/bias partial buffer (reduced by the grouped reduce at the end of backward)"""
         d = self.cfg.d_model
-        nblk = 512
+        nblk = self.LN_BLOCKS
+        lp = ptr(self.g["lnpart"]) if slot is None else ptr(self.g["lnpart_all"]) + 4 * slot * nblk * 2 * d
         call("eg_layernorm_bwd", ptr(dy), ptr(x), ptr(stats), self.fp.p_ptr(gname + ".weight"), ptr(dx), ptr(dx_drop),
-             ptr(self.g["lnpart"]), nblk, self.M, d, self.dtype, d1[0], d1[1], d2[0], d2[1], self.st_ptr, self.stream)
-        lp = ptr(self.g["lnpart"])
+             lp, nblk, self.M, d, self.dtype, d1[0], d1[1], d2[0], d2[1], self.st_ptr, self.stream)
+        if slot is not None:
+            return
         if self.fp.offsets[gname + ".bias"] == self.fp.offsets[gname + ".weight"] + d:   # (gain | bias) back to back
             call("eg_reduce_partials", lp, self.fp.g_ptr(gname + ".weight"), 2 * d, nblk, 2 * d, 0, self.stream)
         else:
@@ -646,11 +662,14 @@ class Engine:
             dYo = g[f"dYo{l}"] if grouped else (g["drm"] if has_drop else g["dr"])
             dh = g[f"dh{l}"] if grouped else g["dh"]
             dqkv = g[f"dqkv{l}"] if grouped else g["dqkv"]
+            s2 = self._ln_slot[pre + "ln2"] if grouped else None
+            s1 = self._ln_slot[pre + "ln1"] if grouped else None
             if has_drop:
-                self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", g["dr"], dYf, d1=(p, sites["ffn_b"]), d2=(p, sites["drop2"]))
+                self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", g["dr"], dYf, d1=(p, sites["ffn_b"]), d2=(p, sites["drop2"]),
+                            slot=s2)
                 dr = g["dr"]
             else:
-                self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", dYf, None)
+                self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", dYf, None, slot=s2)
                 dr = dYf
             if not grouped:
                 self.wgrad(ptr(dYf), ptr(a[f"hff{l}"]), 0, M, d, F, linear=[pre + "ffn.linear2"])
@@ -659,10 +678,10 @@ class Engine:
                 self.wgrad(ptr(dh), ptr(a[f"y1_{l}"]), 0, M, F, d, linear=[pre + "ffn.linear1"])
             self.gemm(ptr(dh), ptr(w[f"w1T{l}"]), ptr(g["dy1"]), M, d, F, residual=ptr(dr))
             if has_drop:
-                self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", g["dr"], dYo, d1=(p, sites["drop1"]))
+                self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", g["dr"], dYo, d1=(p, sites["drop1"]), slot=s1)
                 dr = g["dr"]
             else:
-                self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", dYo, None)
+                self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", dYo, None, slot=s1)
                 dr = dYo
             attn_block_bwd(pre + "mha.", l, a[f"x{l}"], dr, dYo, 0, sites["attn"], other, dqkv, grouped)
             dz, other = other, dz
