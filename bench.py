@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="(default) accepted for compatibility")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: run the RCCL path with a single rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,8 +84,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.share_gpu:
         local_rank = 0
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -110,7 +115,7 @@ def main():
     opt = HipAdamW(model, lr=1e-4, weight_decay=0.01)
     x1, x2, labels = randn_windows(B, C, T, seed=1234 + rank, num_classes=3, device=dev)
     ranges = bucket_ranges(fp.names, fp.offsets, fp.total, model.cfg.num_layers, model.cfg.use_cross_attention)
-    reducer = GradAllReducer(fp.grad, ranges) if world > 1 else None
+    reducer = GradAllReducer(fp.grad, ranges, force=args.force_dist) if use_dist else None
     one = torch.ones(1, device=dev)
 
     from eyegaze_multimodal_amd.graph import GraphedStep
@@ -136,13 +141,13 @@ def main():
     step(0, eager=True)  # first step eagerly: lazy workspace allocation and one-time kernel attributes
     for i in range(args.warmup):
         step(i)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, probe=(graphed is None and i < 8))  # events on the launch stream, read after the region
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -150,7 +155,7 @@ def main():
         for i in range(4):
             step(args.warmup + args.steps + i, probe=True, eager=True)
         torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
@@ -188,7 +193,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(kw, C, T)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -34,16 +34,17 @@ def bucket_ranges(names: List[str], offsets: Dict[str, int], total: int, num_lay
 
 
 class GradAllReducer:
-    def __init__(self, flat_grad: torch.Tensor, ranges: Dict[str, Tuple[int, int]], group=None):
+    def __init__(self, flat_grad: torch.Tensor, ranges: Dict[str, Tuple[int, int]], group=None, force: bool = False):
         self.g, self.ranges, self.group = flat_grad, ranges, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = force and dist.is_initialized()   # exercise the collective path even with one rank (rehearsal)
         self.cuda = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(flat_grad.device) if self.cuda else None
         self.works = []
 
     def on_segment(self, name: str):
         """Called by Engine.backward right after the kernels producing `name`'s gradients were enqueued."""
-        if self.world == 1 or name not in self.ranges:
+        if (self.world == 1 and not self.force) or name not in self.ranges:
             return
         b, e = self.ranges[name]
         if e <= b:
