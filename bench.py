@@ -29,6 +29,7 @@ WORKLOADS = {
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0     # HBM3E, MI355X_MICROARCH.md (about 6.3 TB/s is reachable by a streaming kernel)
 
 
 def cpu_baseline(kw, C, T, seconds_budget=25.0):
@@ -166,17 +167,34 @@ def main():
         ms = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
         # dominant kernel = gemm_nt_kernel (~45 % of the step's GPU time, profiles/): every forward product (strided convs,
-        # q/k/v/out, FFN, heads) and every backward-data product.  achieved = algorithmic FLOPs per launch (2*M*N*K,
-        # averaged over the kernel's launches of a step) / its average launch duration from the HIP events above.
+        # q/k/v/out, FFN, heads) and every backward-data product.  Per launch (averaged over the kernel's launches of a
+        # step): algorithmic FLOPs = 2*M*N*K, algorithmic bytes = each operand/output element once (Engine._gemm_bytes),
+        # duration = HIP events around every launch in the timed region.  With d_model = 256 the products sit BELOW the
+        # ridge (FLOP/B < peak_flops/peak_bw), so the binding roofline is HBM; the MFMA fraction is reported beside it.
         n_launch = len(probes)
-        kms = sum(a.elapsed_time(b) for a, b, _ in probes) / max(n_launch, 1)
-        flops = sum(f for _, _, f in probes) / max(n_launch, 1)
+        kms = sum(a.elapsed_time(b) for a, b, _, _ in probes) / max(n_launch, 1)
+        flops = sum(f for _, _, f, _ in probes) / max(n_launch, 1)
+        nbytes = sum(b for _, _, _, b in probes) / max(n_launch, 1)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        achieved = flops / (kms * 1e-3) / 1e12
+        tflops = flops / (kms * 1e-3) / 1e12
+        gbs = nbytes / (kms * 1e-3) / 1e9
+        ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)
+        hbm_bound = (flops / max(nbytes, 1.0)) < ridge
         traffic = None
         pmc = REPO / "profiles" / "r01_pmc_gemm_nt.json"
         if pmc.exists() and args.workload == "cfg2" and B == 256 and args.dtype == "bf16":
             traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+        per_step = n_launch // (min(8, args.steps) if graphed is None else 4)
+        roof = {"kernel": f"gemm_nt_kernel<{args.dtype}> (all {per_step} launches of a step)",
+                "bound": "hbm" if hbm_bound else "mfma",
+                "achieved": round(gbs if hbm_bound else tflops, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tflops / peak), 4), "traffic": traffic,
+                "launch_ms": round(kms, 5), "algorithmic_bytes_per_launch": round(nbytes),
+                "algorithmic_flops_per_launch": round(flops), "flop_per_byte": round(flops / max(nbytes, 1.0), 1),
+                "ridge_flop_per_byte": round(ridge, 1),
+                "mfma": {"achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4)},
+                "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}}
         out = {
             "metric": "train samples/sec (gaze+EEG windows)", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
@@ -185,10 +203,7 @@ def main():
                        "seq_len": eng.S, "d_model": model.cfg.d_model, "layers": model.cfg.num_layers,
                        "step": "fwd(train,dropout)+bwd+allreduce+clip+AdamW", "parallelism": f"dp{world}",
                        "final_loss": round(loss, 5)},
-            "roofline": {"kernel": f"gemm_nt_kernel<{args.dtype}> (all {n_launch // (min(8, args.steps) if graphed is None else 4)} launches of a step)",
-                         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic, "launch_ms": round(kms, 5),
-                         "algorithmic_flops_per_launch": round(flops)},
+            "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(kw, C, T)

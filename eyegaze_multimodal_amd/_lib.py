@@ -87,6 +87,8 @@ SIGNATURES = {
     "eg_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U, _F, _U, _P, _P],
     "eg_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _P, _P],
     "eg_attention_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _P, _P],
+    "eg_window_normalize": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "eg_attention_probs": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "eg_rows_bcast_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "eg_rows_copy": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "eg_pool_fuse_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -527,3 +527,46 @@ extern "C" int eg_attention_bwd(const void* qkv, const void* ctx, const void* dc
   EG_LAUNCH_CHECK("attention_bwd");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Attention probabilities for the analysis hooks (eeg_metrics.py:433-452 reads them through a forward hook on the
+// attention-dropout module): probs[b, h, q, k] = exp(q.k / sqrt(32) - lse[b, h, q]) in fp32.  Not on the training path.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_probs_kernel(const T* __restrict__ qkv, const float* __restrict__ lse,
+                                                         float* __restrict__ probs, int NB, int S, int H, int kv_shift) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Ql = (float*)smem;   // [S][33]
+  float* Kl = Ql + S * 33;    // [S][33]
+  const int pid = blockIdx.x, b = pid / H, h = pid % H, bk = (b + kv_shift) % NB, D = H * 32;
+  const long long ld = 3ll * D;
+  for (int i = threadIdx.x; i < S * 32; i += blockDim.x) {
+    const int r = i >> 5, d = i & 31;
+    Ql[r * 33 + d] = Elem<T>::ld(qkv + ((long long)b * S + r) * ld + h * 32 + d);
+    Kl[r * 33 + d] = Elem<T>::ld(qkv + ((long long)bk * S + r) * ld + D + h * 32 + d);
+  }
+  __syncthreads();
+  const float* lrow = lse + ((long long)b * H + h) * S;
+  float* out = probs + ((long long)b * H + h) * S * S;
+  for (int i = threadIdx.x; i < S * S; i += blockDim.x) {
+    const int q = i / S, k = i - q * S;
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) acc = fmaf(Ql[q * 33 + d], Kl[k * 33 + d], acc);
+    out[i] = expf(acc * kScale - lrow[q]);
+  }
+}
+
+extern "C" int eg_attention_probs(const void* qkv, const float* lse, float* probs, int NB, int S, int H, int kv_shift,
+                                  int dtype, void* stream) {
+  EG_CHECK(qkv && lse && probs, "eg_attention_probs: null pointer");
+  if (attn_check("eg_attention_probs", NB, S, H, kv_shift, dtype, 0.f, nullptr)) return 1;
+  const int lds = 2 * S * 33 * 4;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EG_F32)
+    hipLaunchKernelGGL(attn_probs_kernel<float>, dim3(NB * H), dim3(256), lds, s, (const float*)qkv, lse, probs, NB, S, H, kv_shift);
+  else
+    hipLaunchKernelGGL(attn_probs_kernel<bf16_t>, dim3(NB * H), dim3(256), lds, s, (const bf16_t*)qkv, lse, probs, NB, S, H, kv_shift);
+  EG_LAUNCH_CHECK("attention_probs");
+  return 0;
+}

@@ -106,11 +106,11 @@ __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
 // hash count matters (the hash is ~60 % of the attention backward's VALU time).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t eg_hash(uint32_t seed_lo, uint32_t seed_hi, uint32_t site, uint32_t idx) {
+  // "lowbias32" finalizer (two multiplies) with the seed's high word folded in between the rounds
   uint32_t x = idx ^ (site * 0x9E3779B9u) ^ seed_lo;
-  x *= 0x85EBCA6Bu; x ^= x >> 13;
-  x += seed_hi;
-  x *= 0xC2B2AE35u; x ^= x >> 16;
-  x *= 0x27D4EB2Fu; x ^= x >> 15;
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15; x += seed_hi;
+  x *= 0x846CA68Bu; x ^= x >> 16;
   return x;
 }
 struct DropCfg {

@@ -262,3 +262,86 @@ extern "C" int eg_pack_convT_weight(const float* w, void* dst, int N, int Cin, i
   EG_LAUNCH_CHECK("pack_convT_weight");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Window normalisation of the data path (1_Data/processed/dual_eeg_dataset.py:142-168, 194-202).
+//   raw [N, 2, C, T] f32 (window n: player-1 channels then player-2 channels, as the shards store them)
+//   -> eeg1 [N, C, T], eeg2 [N, C, T] f32
+//   mode 0 (enable_preprocessing = False, the yaml default): (x - mean(x)) / (std_pop(x) + 1e-8) over the whole window
+//   mode 1 (enable_preprocessing = True): common-average reference (subtract the channel mean at every time step),
+//          then per-channel (v - mean) / (std_pop + 1e-8)
+// One block per (window, player).  Sums run in double: the reference reduces in float32 with pairwise summation, a
+// double accumulator is at least as accurate, and the pass is bandwidth-bound either way (three reads from L2, one write).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+  return s;
+}
+
+__global__ __launch_bounds__(256) void window_normalize_kernel(const float* __restrict__ raw, float* __restrict__ eeg1,
+                                                               float* __restrict__ eeg2, int C, int T, int mode) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[4];
+  float* car = (float*)smem;  // [T] (mode 1)
+  const int n = blockIdx.x >> 1, who = blockIdx.x & 1;
+  const long long CT = (long long)C * T;
+  const float* x = raw + ((long long)n * 2 + who) * CT;
+  float* y = (who ? eeg2 : eeg1) + (long long)n * CT;
+  if (mode == 0) {
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < CT; i += blockDim.x) s += (double)x[i];
+    const double mean = block_sum_d(s, red) / (double)CT;
+    const float meanf = (float)mean;
+    double q = 0.0;
+    for (long long i = threadIdx.x; i < CT; i += blockDim.x) {
+      const double d = (double)x[i] - mean;
+      q += d * d;
+    }
+    const float stdf = (float)sqrt(block_sum_d(q, red) / (double)CT);
+    const float den = stdf + 1e-8f;
+    for (long long i = threadIdx.x; i < CT; i += blockDim.x) y[i] = (x[i] - meanf) / den;
+    return;
+  }
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += x[(long long)c * T + t];
+    car[t] = s / (float)C;
+  }
+  __syncthreads();
+  for (int c = 0; c < C; ++c) {
+    const float* xc = x + (long long)c * T;
+    double s = 0.0;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) s += (double)(xc[t] - car[t]);
+    const double mean = block_sum_d(s, red) / (double)T;
+    const float meanf = (float)mean;
+    double q = 0.0;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+      const double d = (double)(xc[t] - car[t]) - mean;
+      q += d * d;
+    }
+    const float den = (float)sqrt(block_sum_d(q, red) / (double)T) + 1e-8f;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) y[(long long)c * T + t] = ((xc[t] - car[t]) - meanf) / den;
+  }
+}
+
+}  // namespace
+
+extern "C" int eg_window_normalize(const float* raw, float* eeg1, float* eeg2, int N, int C, int T, int mode, void* stream) {
+  EG_CHECK(raw && eeg1 && eeg2, "eg_window_normalize: null pointer");
+  EG_CHECK(N > 0 && C > 0 && T > 0, "eg_window_normalize: bad shape N=%d C=%d T=%d", N, C, T);
+  EG_CHECK(mode == 0 || mode == 1, "eg_window_normalize: mode %d (0 = window z-score, 1 = CAR + channel z-score)", mode);
+  EG_CHECK(T <= 16384, "eg_window_normalize: T=%d exceeds the 16384-sample staging row", T);
+  hipLaunchKernelGGL(window_normalize_kernel, dim3(2 * N), dim3(256), mode ? (size_t)T * 4 : 0, (hipStream_t)stream, raw, eeg1,
+                     eeg2, C, T, mode);
+  EG_LAUNCH_CHECK("window_normalize");
+  return 0;
+}

@@ -10,6 +10,7 @@ All arithmetic runs in libeyegaze_hip.so through `engine.Engine`.  No CPU fallba
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Dict, Optional
 
 import torch
@@ -41,12 +42,32 @@ class _Spectrogram(_Holder):  # D:47-86
         self.proj = nn.Sequential(nn.Linear(1024, 2 * d), nn.ReLU(), nn.Dropout(0.1), nn.Linear(2 * d, d))
 
 
-class _IBSMatrixGenerator(_Holder):  # D:488-525 (no parameters; kept as a named sub-module for hooks)
+class _IBSMatrixGenerator(nn.Module):  # D:488-525, forward D:760-819 (no parameters)
+    """Callable like the reference's generator: `gen(eeg1, eeg2) -> f32 [B, 6, n_feat, C, C]`, computed by the HIP
+    kernels of the owning model's engine.  Inside the model's forward it is invoked only when hooks are registered
+    (the analysis contract of 5_Metrics/eeg_metrics.py:195-205, 335-343); the hot path skips the extra copies."""
+
     def __init__(self, cin, fs, feature_type):
         super().__init__()
         self.in_channels, self.sampling_rate, self.feature_type = cin, fs, feature_type
         self.feature_indices = {"phase": [0, 1, 2, 5], "amplitude": [3, 4, 6]}.get(feature_type, list(range(7)))
         self.num_features = len(self.feature_indices)
+        self._pending = None
+        self._owner = None  # weakref to the DualEEGTransformer (not a registered sub-module)
+
+    def forward(self, eeg1, eeg2):
+        if self._pending is not None:
+            out, self._pending = self._pending, None
+            return out
+        owner = self._owner() if self._owner is not None else None
+        if owner is None:
+            raise L.EgError("ibs_matrix_generator is detached from its model")
+        if not eeg1.is_cuda:
+            raise L.EgError("ibs_matrix_generator (HIP) needs device tensors; there is no CPU fallback")
+        from . import tokens
+        eeg1, eeg2 = eeg1.contiguous().float(), eeg2.contiguous().float()
+        eng = owner.engine(eeg1.shape[0], eeg1.shape[2], eeg1.device)
+        return tokens.ibs_matrices(owner, eng, eeg1, eeg2).clone()
 
 
 class _IBSTokenizer(_Holder):  # D:837-877
@@ -194,6 +215,7 @@ class DualEEGTransformer(nn.Module):
         if use_ibs:
             if use_robust_ibs:
                 self.ibs_matrix_generator = _IBSMatrixGenerator(in_channels, sampling_rate, ibs_feature_type)
+                self.ibs_matrix_generator._owner = weakref.ref(self)
                 self.ibs_tokenizer = _IBSTokenizer(in_channels, d_model, ibs_instance_norm, c.num_ibs_features)
             else:
                 self.ibs_generator = _IBSScalar(d_model)

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -271,12 +272,45 @@ class Engine:
         probe = self.probes.get(tag) if tag else None
         if self.probe_all is not None:      # bench.py: HIP events around EVERY gemm_nt launch of the timed region
             probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            self.probe_all.append((probe[0], probe[1], 2.0 * M * N * K))
+            self.probe_all.append((probe[0], probe[1], 2.0 * M * N * K,
+                                   self._gemm_bytes(M, N, K, a, seg, residual, gate, out_pre)))
         if probe:
             probe[0].record(torch.cuda.current_stream(self.device))
         self._gemm(A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale, seg)
         if probe:
             probe[1].record(torch.cuda.current_stream(self.device))
+
+    def _probs_hook(self, drop_module, qkv, lse, kv_shift):
+        """Analysis contract (5_Metrics/eeg_metrics.py:433-452): a forward hook on an attention-dropout module receives
+        the probabilities [B, H, S, S] as its input, once per stream / direction in the reference's call order.  Only
+        runs when such a hook is registered; the hook's return value does not feed back into the HIP path."""
+        if not (drop_module._forward_hooks or drop_module._forward_pre_hooks):
+            return
+        NB, B, S, H = self.NB, self.B, self.S, self.cfg.num_heads
+        probs = torch.empty(NB, H, S, S, device=self.device, dtype=torch.float32)
+        call("eg_attention_probs", ptr(qkv), ptr(lse), ptr(probs), NB, S, H, kv_shift, self.dtype, self.stream)
+        was = drop_module.training
+        drop_module.training = False      # the module call is only the hook carrier: identity, no torch RNG use
+        try:
+            drop_module(probs[:B])
+            drop_module(probs[B:])
+        finally:
+            drop_module.training = was
+
+    def _gemm_bytes(self, M, N, K, a, seg, residual, gate, out_pre) -> float:
+        """Algorithmic HBM bytes of one gemm_nt launch: every distinct operand element read once, every output element
+        written once (overlapping conv rows count once; the weights count once)."""
+        es = 2 if self.dtype == 0 else 4
+        if a is not None and a.rows_per_group > 0 and not seg[0]:
+            groups = M // a.rows_per_group
+            a_elems = groups * ((a.rows_per_group - 1) * min(a.row_stride, K) + K)
+        elif seg[0]:                       # segmented rows (spectrogram conv): K elements per row drawn from K/seg_len runs
+            a_elems = M * K if a is None else min(M * K, M * max(a.row_stride, 1) + K)
+        else:
+            a_elems = M * K
+        outs = 1 + (1 if out_pre else 0)
+        ins = (1 if residual else 0) + (1 if gate else 0)
+        return float(es * (a_elems + N * K + (outs + ins) * M * N) + 4 * N)
 
     def _gemm(self, A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale,
               seg=(0, 0)):
@@ -352,7 +386,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # grouped weight gradients of the encoder: ONE launch for all 4*L products, ONE reduce launch
     # ------------------------------------------------------------------------------------------
-    GROUP_SPLITS = 5
+    GROUP_SPLITS = int(os.environ.get("EYEGAZE_GROUP_SPLITS", "5"))
     GROUP_MIN_ROWS = 4096   # below this the per-product launches (many splits) are the better shape
 
     def _wgrad_group_plan(self):
@@ -543,6 +577,7 @@ class Engine:
             self.gemm(ptr(x), ptr(w[f"qkv{l}"]), ptr(a[f"qkv{l}"]), M, 3 * d, d, bias=ptr(w[f"bqkv{l}"]))
             call("eg_attention_fwd", ptr(a[f"qkv{l}"]), ptr(a[f"ctx{l}"]), ptr(a[f"lse{l}"]), NB, S, H, 0, self.dtype, p,
                  sites["attn"], self.st_ptr, st)
+            self._probs_hook(self.model.encoder.layers[l].mha.dropout, a[f"qkv{l}"], a[f"lse{l}"], 0)
             self.gemm(ptr(a[f"ctx{l}"]), ptr(w[f"o{l}"]), ptr(a[f"r1_{l}"]), M, d, d, bias=fp.p_ptr(pre + "mha.out_proj.bias"),
                       drop1=(p, sites["drop1"]), residual=ptr(x))
             self.ln_fwd(a[f"r1_{l}"], pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"])
@@ -560,6 +595,7 @@ class Engine:
             self.gemm(ptr(z), ptr(w["qkvx"]), ptr(a["qkvx"]), M, 3 * d, d, bias=ptr(w["bqkvx"]))
             call("eg_attention_fwd", ptr(a["qkvx"]), ptr(a["ctxx"]), ptr(a["lsex"]), NB, S, H, B, self.dtype, p, xs["attn"],
                  self.st_ptr, st)
+            self._probs_hook(self.model.cross_attn.cross_attn.dropout, a["qkvx"], a["lsex"], B)
             self.gemm(ptr(a["ctxx"]), ptr(w["ox"]), ptr(a["rx"]), M, d, d, bias=fp.p_ptr("cross_attn.cross_attn.out_proj.bias"),
                       drop1=(p, xs["drop1"]), residual=ptr(z))
             call("eg_layernorm_fwd", ptr(a["rx"]), fp.p_ptr("cross_attn.norm.weight"), fp.p_ptr("cross_attn.norm.bias"),

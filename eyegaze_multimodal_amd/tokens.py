@@ -142,6 +142,32 @@ def pack(model, eng: Engine):
 
 
 # ------------------------------------------------------------------------------------------------
+def ibs_analytic(eng: Engine, eeg1, eeg2):
+    """Band-passed signals, Hilbert phases and per-signal statistics of all 2B*C signals (D:527-591)."""
+    ib, a = eng.ib, eng.a
+    lo, hi, nb = _bands(eng, ib["bands"])
+    xcat = torch.cat([eeg1, eeg2], 0)  # [NB, C, T] player-1 windows then player-2 windows (device copy, plumbing)
+    eng._keep = xcat
+    call("eg_ibs_analytic", ptr(xcat), ptr(a["ib_xb"]), ptr(a["ib_ph"]), ptr(a["ib_stats"]), ptr(a["ib_spec"]), ib["nsig"], eng.T,
+         float(eng.cfg.sampling_rate), ib["nbin"], lo, hi, nb, eng.stream)
+
+
+def ibs_pairs(eng: Engine):
+    """[B, 6, 7, C, C] connectivity matrices from the analytic signals (D:593-819)."""
+    ib, a = eng.ib, eng.a
+    lo, hi, nb = _bands(eng, ib["bands"])
+    call("eg_ibs_pairs", ptr(a["ib_xb"]), ptr(a["ib_ph"]), ptr(a["ib_stats"]), ptr(a["ib_spec"]), ptr(a["ib_conn"]), eng.B, eng.C,
+         eng.T, float(eng.cfg.sampling_rate), ib["nbin"], lo, hi, nb, eng.stream)
+
+
+def ibs_matrices(model, eng: Engine, eeg1, eeg2) -> torch.Tensor:
+    """Stand-alone call of the matrix generator (what `model.ibs_matrix_generator(eeg1, eeg2)` returns, D:760-819)."""
+    _alloc(model, eng)
+    ibs_analytic(eng, eeg1, eeg2)
+    ibs_pairs(eng)
+    return eng.a["ib_conn"].index_select(2, eng.a["ib_fidx"].long())
+
+
 def forward(model, eng: Engine, eeg1, eeg2, train: bool):
     cfg = eng.cfg
     if not (cfg.use_spectrogram or cfg.use_ibs):
@@ -152,15 +178,19 @@ def forward(model, eng: Engine, eeg1, eeg2, train: bool):
     if cfg.use_ibs:
         ib = eng.ib
         lo, hi, nb = _bands(eng, ib["bands"])
-        xcat = torch.cat([eeg1, eeg2], 0)  # [NB, C, T] player-1 windows then player-2 windows (device copy, plumbing)
-        eng._keep = xcat
         fs = float(cfg.sampling_rate)
-        call("eg_ibs_analytic", ptr(xcat), ptr(a["ib_xb"]), ptr(a["ib_ph"]), ptr(a["ib_stats"]), ptr(a["ib_spec"]), ib["nsig"], T,
-             fs, ib["nbin"], lo, hi, nb, st)
+        ibs_analytic(eng, eeg1, eeg2)
         if cfg.use_robust_ibs:
             ntok, E = cfg.num_ibs_tokens, Cn * Cn
-            call("eg_ibs_pairs", ptr(a["ib_xb"]), ptr(a["ib_ph"]), ptr(a["ib_stats"]), ptr(a["ib_spec"]), ptr(a["ib_conn"]), B, Cn,
-                 T, fs, ib["nbin"], lo, hi, nb, st)
+            ibs_pairs(eng)
+            gen = model.ibs_matrix_generator
+            if gen._forward_hooks or gen._forward_pre_hooks:
+                # analysis contract (5_Metrics/eeg_metrics.py:195-205, 335-343): a forward hook on `ibs_matrix_generator`
+                # sees the [B, 6, n_feat, C, C] matrices and may edit them in place or return a replacement
+                idx = a["ib_fidx"].long()
+                gen._pending = a["ib_conn"].index_select(2, idx)
+                out = gen(eeg1, eeg2)
+                a["ib_conn"].index_copy_(2, idx, out.to(device=eng.device, dtype=torch.float32))
             pre = "ibs_tokenizer."
             inorm = cfg.ibs_instance_norm
             call("eg_ibs_inorm", ptr(a["ib_conn"]), ptr(a["ib_fidx"]), fp.p_ptr(pre + "instance_norm.weight") if inorm else 0,

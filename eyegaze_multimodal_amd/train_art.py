@@ -33,7 +33,7 @@ if __package__ in (None, ""):
     __package__ = "eyegaze_multimodal_amd"
 
 from . import DualEEGTransformer, HipAdamW  # noqa: E402
-from .data import synth_windows  # noqa: E402
+from .data import WindowShards, build_window_shards, synth_windows  # noqa: E402
 from .ddp import GradAllReducer, broadcast_params, bucket_ranges, shard_indices  # noqa: E402
 
 logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(name)s - %(levelname)s - %(message)s")
@@ -171,6 +171,39 @@ class Trainer:
         return m
 
 
+def split_items(items, test_size: float, seed: int):
+    """Item-level train/test split of the metadata rows (reference: HF `Dataset.train_test_split(test_size, seed)`,
+    train_art.py:93-109 — its stratified attempt raises on a string column and falls back to the plain split).  Uses the
+    same library call when `datasets` is importable so that the split is the reference's; otherwise a seeded permutation
+    (documented difference)."""
+    try:
+        from datasets import Dataset
+        sp = Dataset.from_list(list(items)).train_test_split(test_size=test_size, seed=seed)
+        return list(sp["train"]), list(sp["test"])
+    except ImportError:
+        perm = np.random.default_rng(seed).permutation(len(items))
+        n_test = int(np.ceil(len(items) * test_size))
+        return [items[i] for i in perm[n_test:]], [items[i] for i in perm[:n_test]]
+
+
+def prepare_shards(config: Dict[str, Any], out_dir: Path, rank: int = 0, world: int = 1) -> Dict[str, Path]:
+    """CSV recordings -> windowed shards, once (rank 0 builds; the others wait on the barrier)."""
+    import json
+    d = config["data"]
+    dirs = {"train": out_dir / "train", "test": out_dir / "test"}
+    if rank == 0 and not all((p / "index.json").exists() for p in dirs.values()):
+        items = json.loads(Path(d["metadata_path"]).read_text())
+        if d.get("max_samples"):
+            items = items[: d["max_samples"]]
+        train_items, test_items = split_items(items, d["train_test_split"], d["random_seed"])
+        for name, its in (("train", train_items), ("test", test_items)):
+            idx = build_window_shards(its, d["eeg_base_path"], d["label2id"], dirs[name], d["window_size"], d["stride"])
+            logger.info(f"{name}: {len(its)} recordings -> {idx['count']} windows in {len(idx['shards'])} shards")
+    if world > 1:
+        dist.barrier()
+    return dirs
+
+
 def _batches(x1, x2, y, bs, device, idx):
     for i in range(0, len(idx) - bs + 1, bs):
         j = idx[i:i + bs]
@@ -192,16 +225,18 @@ def main(args):
     tr = Trainer(config, device, rank, world, args.dtype)
     d, t = config["data"], config["training"]
     C, T, ncls = config["model"]["in_channels"], d["window_size"], config["model"]["num_labels"]
-    n_total = d.get("max_samples") or d.get("synthetic_samples", 2048)
     eeg_dir = Path(d.get("eeg_base_path", ""))
-    if not d.get("synthetic", False) and eeg_dir.exists() and any(eeg_dir.glob("*.csv")):
-        raise SystemExit("CSV loading is the reference's data path (1_Data/processed/dual_eeg_dataset.py); this build "
-                         "trains on pre-windowed tensors — convert the CSVs offline or set data.synthetic: true")
-    logger.info(f"synthetic class-conditional windows: n={n_total} C={C} T={T} classes={ncls}")
-    x1, x2, y = synth_windows(n_total, C, T, ncls, fs=d["sampling_rate"], seed=d["random_seed"])
-    n_test = int(round(n_total * d["train_test_split"]))
-    perm = np.random.default_rng(d["random_seed"]).permutation(n_total)
-    test_idx, train_idx = perm[:n_test], perm[n_test:]
+    use_csv = not d.get("synthetic", False) and eeg_dir.exists() and any(eeg_dir.glob("*.csv"))
+    shards = None
+    if use_csv:
+        shards = prepare_shards(config, Path(t["output_dir"]) / "window_shards", rank, world)
+    else:
+        n_total = d.get("max_samples") or d.get("synthetic_samples", 2048)
+        logger.info(f"synthetic class-conditional windows: n={n_total} C={C} T={T} classes={ncls}")
+        x1, x2, y = synth_windows(n_total, C, T, ncls, fs=d["sampling_rate"], seed=d["random_seed"])
+        n_test = int(round(n_total * d["train_test_split"]))
+        perm = np.random.default_rng(d["random_seed"]).permutation(n_total)
+        test_idx, train_idx = perm[:n_test], perm[n_test:]
     bs, ebs = t["per_device_train_batch_size"], t["per_device_eval_batch_size"]
     out_dir = Path(t["output_dir"])
     if rank == 0:
@@ -219,19 +254,29 @@ def main(args):
     best_f1, best_epoch = 0.0, 0
     for epoch in range(tr.epochs):
         tr.opt.set_epoch(epoch, tr.epochs)           # CosineAnnealingLR stepped per epoch (train_art.py:409,494)
-        rng = np.random.default_rng(d["random_seed"] + epoch)
-        order = rng.permutation(train_idx)
-        gbs = bs * world
         sums, nb = {}, 0
-        for i in range(0, len(order) - gbs + 1, gbs):
-            mine = order[i:i + gbs][list(shard_indices(gbs, rank, world))]
-            losses = tr.train_step(x1[mine].to(device), x2[mine].to(device), y[mine].to(device))
+        if shards is not None:
+            train_ld = WindowShards(shards["train"], bs, device, rank, world, shuffle=True, seed=d["random_seed"],
+                                    preprocessing=d.get("enable_preprocessing", False), drop_last=True)
+            train_ld.set_epoch(epoch)
+            train_iter = ((b["eeg1"], b["eeg2"], b["labels"]) for b in train_ld)
+        else:
+            order = np.random.default_rng(d["random_seed"] + epoch).permutation(train_idx)
+            gbs = bs * world
+            train_iter = ((x1[m].to(device), x2[m].to(device), y[m].to(device)) for m in
+                          (order[i:i + gbs][list(shard_indices(gbs, rank, world))] for i in range(0, len(order) - gbs + 1, gbs)))
+        for e1, e2, lab in train_iter:
+            losses = tr.train_step(e1, e2, lab)
             for k, v in losses.items():
                 sums[k] = sums.get(k, 0.0) + v.float()
             nb += 1
         train_metrics = {f"train/{k}": float(v) / max(nb, 1) for k, v in sums.items()}
-        my_test = test_idx[list(shard_indices(len(test_idx), rank, world))]
-        ev = tr.evaluate(_batches(x1, x2, y, min(ebs, max(1, len(my_test))), device, my_test))
+        if shards is not None:
+            test_ld = WindowShards(shards["test"], ebs, device, rank, world, preprocessing=d.get("enable_preprocessing", False))
+            ev = tr.evaluate((b["eeg1"], b["eeg2"], b["labels"]) for b in test_ld)
+        else:
+            my_test = test_idx[list(shard_indices(len(test_idx), rank, world))]
+            ev = tr.evaluate(_batches(x1, x2, y, min(ebs, max(1, len(my_test))), device, my_test))
         metrics = {**train_metrics, **ev, "epoch": epoch + 1}
         if rank == 0:
             logger.info(" ".join(f"{k}: {v:.4f}" for k, v in metrics.items() if k != "epoch") + f" (epoch {epoch + 1}/{tr.epochs})")

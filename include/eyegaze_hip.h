@@ -69,6 +69,11 @@ typedef struct eg_rowmap {
  * ------------------------------------------------------------------------------------------- */
 int eg_window_pack(const float* x, void* xt, int NB, int C, int T, int Cp, int pad_front, int Tp, int dtype,
                    void* stream);
+/* data-path normalisation (1_Data/processed/dual_eeg_dataset.py:142-168 when enable_preprocessing, :201-202 otherwise):
+ *   raw [N, 2, C, T] f32 (player-1 window, player-2 window) -> eeg1, eeg2 [N, C, T] f32
+ *   mode 0: per-window global z-score, population std + 1e-8
+ *   mode 1: common-average reference, then per-channel z-score, population std + 1e-8 */
+int eg_window_normalize(const float* raw, float* eeg1, float* eeg2, int N, int C, int T, int mode, void* stream);
 
 /* Parameter staging (fp32 master -> compute dtype copies), run once per optimiser step.
  *   eg_cast:             n contiguous elements
@@ -191,6 +196,10 @@ int eg_attention_fwd(const void* qkv, void* ctx, float* lse, int NB, int S, int 
 int eg_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int NB, int S,
                      int H, int kv_shift, int dtype, float drop_p, uint32_t drop_site, const eg_step_state* state,
                      void* stream);
+/* probs[NB, H, S, S] (fp32) = softmax rows recomputed from qkv and the forward's lse: what a forward hook on the
+ * attention-dropout module receives as input (5_Metrics/eeg_metrics.py:433-452).  Analysis only. */
+int eg_attention_probs(const void* qkv, const float* lse, float* probs, int NB, int S, int H, int kv_shift, int dtype,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sequence assembly and heads (all [B, d]-sized, latency-bound single launches)

@@ -317,12 +317,15 @@ def encoder(x: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, p_drop: float = 0.0
     return _ln(x, sd, "encoder.norm.")
 
 
-def cross_brain_attention(z1: Tensor, z2: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, p_drop: float = 0.0):
+def cross_brain_attention(z1: Tensor, z2: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, p_drop: float = 0.0,
+                          probs: Optional[list] = None):
     """Both directions share one MHA and one LN and read the pre-update z1, z2 (D:966-974)."""
     def drop(t):
         return F.dropout(t, p_drop, True) if p_drop > 0 else t
-    c1 = mha(z1, z2, sd, "cross_attn.cross_attn.", cfg.num_heads, p_drop)
-    c2 = mha(z2, z1, sd, "cross_attn.cross_attn.", cfg.num_heads, p_drop)
+    c1, p1 = mha(z1, z2, sd, "cross_attn.cross_attn.", cfg.num_heads, p_drop, return_probs=True)
+    c2, p2 = mha(z2, z1, sd, "cross_attn.cross_attn.", cfg.num_heads, p_drop, return_probs=True)
+    if probs is not None:
+        probs.extend([p1, p2])
     return _ln(z1 + drop(c1), sd, "cross_attn.norm."), _ln(z2 + drop(c2), sd, "cross_attn.norm.")
 
 
@@ -331,9 +334,10 @@ def cross_brain_attention(z1: Tensor, z2: Tensor, sd: Dict[str, Tensor], cfg: Mo
 # --------------------------------------------------------------------------------------
 
 def forward(eeg1: Tensor, eeg2: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, labels: Optional[Tensor] = None,
-            train: bool = False, stages: Optional[dict] = None) -> Dict[str, Tensor]:
+            train: bool = False, stages: Optional[dict] = None, conn_edit=None) -> Dict[str, Tensor]:
     """Restates DualEEGTransformer.forward.  `stages`, when given, receives the intermediates the
-    golden fixtures pin (temporal tokens, connectivity, ibs/spec tokens, encoder and cross-attn outputs)."""
+    golden fixtures pin (temporal tokens, connectivity, ibs/spec tokens, encoder and cross-attn outputs).
+    `conn_edit(conn) -> conn` stands in for a forward hook on the matrix generator (eeg_metrics.py:335-343)."""
     B = eeg1.shape[0]
     p = cfg.dropout if train else 0.0
     p01 = 0.1 if train else 0.0  # hard-coded sites D:161, D:84, D:866, D:216
@@ -343,6 +347,8 @@ def forward(eeg1: Tensor, eeg2: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, la
     if cfg.use_ibs:
         if cfg.use_robust_ibs:
             conn = ibs_connectivity(eeg1, eeg2, cfg)
+            if conn_edit is not None:
+                conn = conn_edit(conn)
             ibs_tokens = ibs_tokenize(conn, sd, cfg, p01)
             if stages is not None:
                 stages["connectivity"] = conn
@@ -372,7 +378,10 @@ def forward(eeg1: Tensor, eeg2: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, la
         if ibs_tokens is not None:
             stages["ibs_tokens"] = ibs_tokens
     if cfg.use_cross_attention:
-        z1c, z2c = cross_brain_attention(z1, z2, sd, cfg, p)
+        xp = [] if stages is not None else None
+        z1c, z2c = cross_brain_attention(z1, z2, sd, cfg, p, probs=xp)
+        if stages is not None:
+            stages["xattn_probs"] = torch.stack(xp)          # [direction, B, H, S, S]: what a dropout-module hook sees
     else:
         z1c, z2c = z1, z2
     if stages is not None:
@@ -576,3 +585,23 @@ def synthetic_state_dict(cfg: ModelCfg, seed: int) -> Dict[str, Tensor]:
 def zscore_window(x: np.ndarray) -> np.ndarray:
     """Per-window GLOBAL z-score with population std (1_Data/processed/dual_eeg_dataset.py:201-202)."""
     return ((x - x.mean()) / (x.std() + 1e-8)).astype(np.float32)
+
+
+def preprocess_window(x: np.ndarray) -> np.ndarray:
+    """`enable_preprocessing=True` branch (1_Data/processed/dual_eeg_dataset.py:142-168): the band-pass step there is a
+    TODO that does nothing; common-average reference, then per-channel z-score with population std + 1e-8."""
+    x = x - x.mean(axis=0, keepdims=True)
+    return ((x - x.mean(axis=1, keepdims=True)) / (x.std(axis=1, keepdims=True) + 1e-8)).astype(np.float32)
+
+
+def enumerate_windows(lengths, window_size: int, stride: int):
+    """(item index, start, end) in the order DualEEGDataset._prepare_windows emits them (dual_eeg_dataset.py:62-120);
+    `lengths[i]` = min(len(player1), len(player2)) of item i, or None when a file is missing."""
+    out = []
+    for idx, n in enumerate(lengths):
+        if n is None or n < window_size:
+            continue
+        for w in range((n - window_size) // stride + 1):
+            if w * stride + window_size <= n:
+                out.append((idx, w * stride, w * stride + window_size))
+    return out

@@ -73,3 +73,36 @@ def test_trainer_with_aux_losses_and_ibs(tmp_path):
     assert {"loss_ce", "loss_ibs_cls", "loss_sym", "loss_ibs_contrastive"} <= set(losses[0])
     ev = tr.evaluate([(x1.cuda(), x2.cuda(), y.cuda())])
     assert set(ev) == {"eval/accuracy", "eval/precision", "eval/recall", "eval/f1", "eval/loss"}
+
+
+def test_train_script_on_csv_recordings(tmp_path):
+    """The CSV data path end to end: recordings on disk + metadata JSON in the reference's layout ->
+    windowed shards -> device-side normalisation -> train/eval epochs.  Real recordings are absent from the reference
+    tree, so the CSVs are synthetic (class-specific rhythm, as data.synth_windows)."""
+    import json
+    rng = np.random.default_rng(0)
+    eeg = tmp_path / "EEGseg"
+    eeg.mkdir()
+    names = ["Single", "Competition", "Cooperation"]
+    items, tt = [], np.arange(1024 + 3 * 512) / 256.0
+    for i in range(30):
+        c = i % 3
+        for who in (1, 2):
+            x = 1e-5 * rng.standard_normal((8, len(tt))) + 2e-5 * np.sin(2 * np.pi * [6.0, 14.0, 31.0][c] * tt + rng.uniform(0, 6.28))
+            np.savetxt(eeg / f"pair{i}_p{who}.csv", x.astype(np.float32), delimiter=",", fmt="%.7e")
+        items.append({"player1": f"pair{i}_p1", "player2": f"pair{i}_p2", "class": names[c]})
+    (tmp_path / "meta.json").write_text(json.dumps(items))
+    cfg = make_config(tmp_path, data={"synthetic": False, "metadata_path": str(tmp_path / "meta.json"), "eeg_base_path": str(eeg),
+                                      "max_samples": None},
+                      model={"num_layers": 2}, training={"num_train_epochs": 5, "per_device_train_batch_size": 16,
+                                                          "per_device_eval_batch_size": 16, "learning_rate": 5.0e-4})
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    res = subprocess.run([sys.executable, str(REPO / "eyegaze_multimodal_amd" / "train_art.py"), "--config", str(path)],
+                         capture_output=True, text=True, cwd=str(REPO), timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    idx = json.loads((tmp_path / "run" / "window_shards" / "train" / "index.json").read_text())
+    tst = json.loads((tmp_path / "run" / "window_shards" / "test" / "index.json").read_text())
+    assert idx["count"] + tst["count"] == 30 * 4 and tst["count"] == 6 * 4      # 4 windows per recording, 20 % of the items held out
+    ck = torch.load(tmp_path / "run" / "best_model.pt", weights_only=False)
+    assert ck["best_f1"] > 0.55, res.stderr[-2000:]
