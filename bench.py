@@ -67,8 +67,8 @@ def cpu_baseline(kw, C, T, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=256, help="windows pairs per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="(default) accepted for compatibility")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
+    ap.add_argument("--probe-dump", default=None, help="write the per-launch gemm_nt timings (shape, us, TFLOP/s, GB/s) to this file")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: run the RCCL path with a single rank")
     args = ap.parse_args()
 
@@ -172,9 +173,9 @@ def main():
         # duration = HIP events around every launch in the timed region.  With d_model = 256 the products sit BELOW the
         # ridge (FLOP/B < peak_flops/peak_bw), so the binding roofline is HBM; the MFMA fraction is reported beside it.
         n_launch = len(probes)
-        kms = sum(a.elapsed_time(b) for a, b, _, _ in probes) / max(n_launch, 1)
-        flops = sum(f for _, _, f, _ in probes) / max(n_launch, 1)
-        nbytes = sum(b for _, _, _, b in probes) / max(n_launch, 1)
+        kms = sum(a.elapsed_time(b) for a, b, *_ in probes) / max(n_launch, 1)
+        flops = sum(f for _, _, f, *_ in probes) / max(n_launch, 1)
+        nbytes = sum(b for _, _, _, b, *_ in probes) / max(n_launch, 1)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         tflops = flops / (kms * 1e-3) / 1e12
         gbs = nbytes / (kms * 1e-3) / 1e9
@@ -185,6 +186,15 @@ def main():
         if pmc.exists() and args.workload == "cfg2" and B == 256 and args.dtype == "bf16":
             traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
         per_step = n_launch // (min(8, args.steps) if graphed is None else 4)
+        if args.probe_dump:
+            rows = []
+            for j in range(per_step):
+                sel = probes[j::per_step]
+                us = 1e3 * sum(a.elapsed_time(b) for a, b, *_ in sel) / len(sel)
+                _, _, f, nb, shape = sel[0]
+                rows.append({"launch": j, "M": shape[0], "N": shape[1], "K": shape[2], "us": round(us, 2),
+                             "tflops": round(f / us / 1e6, 1), "gbs": round(nb / us / 1e3, 1)})
+            Path(args.probe_dump).write_text(json.dumps(rows, indent=0))
         roof = {"kernel": f"gemm_nt_kernel<{args.dtype}> (all {per_step} launches of a step)",
                 "bound": "hbm" if hbm_bound else "mfma",
                 "achieved": round(gbs if hbm_bound else tflops, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,

@@ -273,7 +273,7 @@ class Engine:
         if self.probe_all is not None:      # bench.py: HIP events around EVERY gemm_nt launch of the timed region
             probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.probe_all.append((probe[0], probe[1], 2.0 * M * N * K,
-                                   self._gemm_bytes(M, N, K, a, seg, residual, gate, out_pre)))
+                                   self._gemm_bytes(M, N, K, a, seg, residual, gate, out_pre), (M, N, K)))
         if probe:
             probe[0].record(torch.cuda.current_stream(self.device))
         self._gemm(A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale, seg)
@@ -300,7 +300,7 @@ class Engine:
     def _gemm_bytes(self, M, N, K, a, seg, residual, gate, out_pre) -> float:
         """Algorithmic HBM bytes of one gemm_nt launch: every distinct operand element read once, every output element
         written once (overlapping conv rows count once; the weights count once)."""
-        es = 2 if self.dtype == 0 else 4
+        es = self.es
         if a is not None and a.rows_per_group > 0 and not seg[0]:
             groups = M // a.rows_per_group
             a_elems = groups * ((a.rows_per_group - 1) * min(a.row_stride, K) + K)

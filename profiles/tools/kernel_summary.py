@@ -1,6 +1,6 @@
 import csv, collections, sys, glob
 d = sys.argv[1]
-f = glob.glob(d + '/**/*_kernel_trace.csv', recursive=True)[0]
+f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1
 agg = collections.defaultdict(list)

@@ -26,13 +26,16 @@ def bench_nt(M, N, K, residual=False, bias=True, act=0, reps=30, dtype=L.EG_BF16
     byt = (M * K + M * N * (2 if residual else 1)) * es
     print(f"NT M={M:6d} N={N:5d} K={K:5d} res={int(residual)} : {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TF/s  {byt/us/1e6:6.2f} TB/s  blocks={((M+127)//128)*((N+127)//128)}")
 
-for M in (32768, 33280, 16384, 65536):
-    bench_nt(M, 256, 256, residual=True)
-bench_nt(33280, 256, 256, residual=False)
-bench_nt(33280, 256, 1024, residual=True)
-bench_nt(33280, 256, 768, residual=True)
-bench_nt(33280, 768, 256)
-bench_nt(33280, 1024, 256, act=1)
-bench_nt(32768, 1024, 256, act=1)
+print("-- fixed cost vs per-iteration cost (N=256, plain epilogue) --")
+for M in (128, 2048, 16640, 33280):
+    for K in (128, 256, 512, 1024):
+        bench_nt(M, 256, K, residual=False, bias=True)
+print("-- epilogue variants at M=33280 N=256 K=256 --")
+bench_nt(33280, 256, 256, residual=False, bias=False)
+bench_nt(33280, 256, 256, residual=True, bias=True)
+print("-- N scaling at K=256 --")
+for N in (128, 256, 512, 768, 1024):
+    bench_nt(33280, N, 256)
+print("-- misc --")
 bench_nt(32768, 256, 6400)
 bench_nt(8192, 8192, 8192)
