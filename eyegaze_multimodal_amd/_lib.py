@@ -13,7 +13,7 @@ LIB_PATH = _PKG / "libeyegaze_hip.so"
 
 EG_F32, EG_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class EgError(RuntimeError):
@@ -40,7 +40,11 @@ class GemmDesc(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldw", C.c_int32),
                 ("act", C.c_int32), ("dtype", C.c_int32),
                 ("drop1_p", C.c_float), ("drop2_p", C.c_float), ("drop1_site", C.c_uint32), ("drop2_site", C.c_uint32),
-                ("gate_scale", C.c_float), ("a_seg_len", C.c_int32), ("a_seg_stride", C.c_int64)]
+                ("gate_scale", C.c_float), ("a_seg_len", C.c_int32), ("a_seg_stride", C.c_int64),
+                ("ln_mode", C.c_int32), ("row_tile", C.c_int32), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
+                ("ln_x", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_out", C.c_void_p), ("ln_out2", C.c_void_p),
+                ("ln_partial", C.c_void_p), ("ln_drop1_p", C.c_float), ("ln_drop2_p", C.c_float),
+                ("ln_drop1_site", C.c_uint32), ("ln_drop2_site", C.c_uint32)]
 
 
 class PackEntry(C.Structure):

@@ -129,6 +129,11 @@ class Engine:
         self.fp: FlatParams = model._flat
         self.stream = 0
         self.probes = {}   # tag -> (start_event, end_event) recorded around that launch
+        # LayerNorm forward / backward run in the epilogue of the adjacent N == d_model product (row-complete GEMM tile)
+        self.fuse_ln = cfg.d_model == 256 and os.environ.get("EYEGAZE_FUSE_LN", "0") == "1"
+        self.ln_nblk_cap = max(self.LN_BLOCKS, (self.M + 63) // 64)
+        if (self.M + 63) // 64 > 2048:
+            self.fuse_ln = False      # the scratch partial buffer holds 2048 workgroups
         self.probe_all = None  # list of (start, end, flops) for every gemm_nt launch when bench.py enables it
         self._alloc()
         self.packed_version = -1
@@ -268,15 +273,17 @@ class Engine:
     # thin wrappers
     # ------------------------------------------------------------------------------------------
     def gemm(self, A, W, Cout, M, N, K, *, a=None, c=None, r=None, p=None, ldw=None, bias=0, residual=0, gate=0,
-             out_pre=0, act=0, drop1=(0.0, 0), drop2=(0.0, 0), gate_scale=1.0, tag=None, seg=(0, 0)):
+             out_pre=0, act=0, drop1=(0.0, 0), drop2=(0.0, 0), gate_scale=1.0, tag=None, seg=(0, 0), ln=None):
+        """ln: LayerNorm fused into the epilogue of an N == 256 product (eg_gemm_desc.ln_*):
+        dict(mode=1, gamma, beta, out, stats) or dict(mode=2, gamma, x, stats, out, out2, partial, d1, d2)."""
         probe = self.probes.get(tag) if tag else None
         if self.probe_all is not None:      # bench.py: HIP events around EVERY gemm_nt launch of the timed region
             probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.probe_all.append((probe[0], probe[1], 2.0 * M * N * K,
-                                   self._gemm_bytes(M, N, K, a, seg, residual, gate, out_pre), (M, N, K)))
+                                   self._gemm_bytes(M, N, K, a, seg, residual, gate, out_pre, ln, Cout), (M, N, K)))
         if probe:
             probe[0].record(torch.cuda.current_stream(self.device))
-        self._gemm(A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale, seg)
+        self._gemm(A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale, seg, ln)
         if probe:
             probe[1].record(torch.cuda.current_stream(self.device))
 
@@ -297,7 +304,7 @@ class Engine:
         finally:
             drop_module.training = was
 
-    def _gemm_bytes(self, M, N, K, a, seg, residual, gate, out_pre) -> float:
+    def _gemm_bytes(self, M, N, K, a, seg, residual, gate, out_pre, ln=None, Cout=1) -> float:
         """Algorithmic HBM bytes of one gemm_nt launch: every distinct operand element read once, every output element
         written once (overlapping conv rows count once; the weights count once)."""
         es = self.es
@@ -308,15 +315,26 @@ class Engine:
             a_elems = M * K if a is None else min(M * K, M * max(a.row_stride, 1) + K)
         else:
             a_elems = M * K
-        outs = 1 + (1 if out_pre else 0)
+        outs = (1 if Cout else 0) + (1 if out_pre else 0)
         ins = (1 if residual else 0) + (1 if gate else 0)
+        if ln:      # fused LayerNorm: its output row(s), and in backward the saved input row
+            outs += 1 + (1 if ln.get("out2") else 0)
+            ins += 1 if ln["mode"] == 2 else 0
         return float(es * (a_elems + N * K + (outs + ins) * M * N) + 4 * N)
 
     def _gemm(self, A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale,
-              seg=(0, 0)):
+              seg=(0, 0), ln=None):
         dsc = GemmDesc()
+        if ln:
+            dsc.ln_mode, dsc.ln_gamma, dsc.ln_stats, dsc.ln_out = ln["mode"], ln["gamma"], ln["stats"], ln["out"]
+            if ln["mode"] == 1:
+                dsc.ln_beta = ln["beta"]
+            else:
+                dsc.ln_x, dsc.ln_out2, dsc.ln_partial = ln["x"], ln.get("out2") or None, ln["partial"]
+                dsc.ln_drop1_p, dsc.ln_drop1_site = ln.get("d1", (0.0, 0))
+                dsc.ln_drop2_p, dsc.ln_drop2_site = ln.get("d2", (0.0, 0))
         dsc.a_seg_len, dsc.a_seg_stride = seg
-        dsc.A, dsc.W, dsc.C = A, W, Cout
+        dsc.A, dsc.W, dsc.C = A, W, Cout or None
         dsc.bias, dsc.residual, dsc.gate, dsc.out_pre = bias or None, residual or None, gate or None, out_pre or None
         dsc.state = self.st_ptr
         dsc.a = a or rowmap(K)
@@ -420,7 +438,7 @@ class Engine:
         ln_names = [f"encoder.layers.{l}.{n}" for l in range(cfg.num_layers) for n in ("ln1", "ln2")]
         if not all(fp.offsets[n + ".bias"] == fp.offsets[n + ".weight"] + d for n in ln_names):
             return None
-        g["lnpart_all"] = self._t(len(ln_names) * self.LN_BLOCKS * 2 * d, dtype=torch.float32)
+        g["lnpart_all"] = self._t(len(ln_names) * self.ln_nblk_cap * 2 * d, dtype=torch.float32)
         self._ln_slot = {n: i for i, n in enumerate(ln_names)}
         tp = (L.TNProblem * len(probs))()
         rt = (L.ReduceEntry * (len(probs) + len(ln_names)))()
@@ -436,8 +454,11 @@ class Engine:
             off += splits * slab
         for i, n in enumerate(ln_names):   # deferred LayerNorm gain / bias partials ride in the same reduce launch
             r = rt[len(probs) + i]
-            r.partial, r.out = ptr(g["lnpart_all"]) + 4 * i * self.LN_BLOCKS * 2 * d, fp.g_ptr(n + ".weight")
-            r.n, r.stride, r.splits, r.blk0 = 2 * d, 2 * d, self.LN_BLOCKS, rblk
+            r.partial, r.out = ptr(g["lnpart_all"]) + 4 * i * self.ln_nblk_cap * 2 * d, fp.g_ptr(n + ".weight")
+            # LayerNorms whose backward runs in a GEMM epilogue leave one partial per 64-row workgroup; the top layer's ln2
+            # keeps the stand-alone kernel (its input gradient comes from encoder.norm, not from a product)
+            fused = self.fuse_ln and not n.endswith(f"layers.{cfg.num_layers - 1}.ln2")
+            r.n, r.stride, r.splits, r.blk0 = 2 * d, 2 * d, ((M + 63) // 64 if fused else self.LN_BLOCKS), rblk
             rblk += (2 * d // 4 + 7) // 8
         dev = lambda arr: torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
         self._wg_plan = dict(tp=dev(tp), rt=dev(rt), n=len(probs), nr=len(probs) + len(ln_names), blocks=blk, rblocks=rblk,
@@ -449,6 +470,30 @@ class Engine:
         call("eg_gemm_tn_grouped", ptr(pl["tp"]), pl["n"], pl["blocks"], self.M, pl["splits"], self.dtype, self.stream)
         call("eg_reduce_table", ptr(pl["rt"]), pl["nr"], pl["rblocks"], self.stream)
 
+    def _ln_f(self, gname, y, stats):
+        """forward LayerNorm spec for gemm(ln=...) — None when the fused epilogue is unavailable (d_model != 256)"""
+        if not self.fuse_ln:
+            return None
+        return dict(mode=1, gamma=self.fp.p_ptr(gname + ".weight"), beta=self.fp.p_ptr(gname + ".bias"), out=ptr(y), stats=ptr(stats))
+
+    def _ln_b(self, gname, x, stats, dx, dx_drop, d1=(0.0, 0), d2=(0.0, 0), slot=None):
+        """backward LayerNorm spec for gemm(ln=...); the per-workgroup gain/bias partials go to the slot's deferred buffer
+        (grouped reduce) or to the scratch buffer that `_ln_b_finish` reduces right after the product"""
+        d, nblk = self.cfg.d_model, (self.M + 63) // 64
+        lp = ptr(self.g["lnpart"]) if slot is None else ptr(self.g["lnpart_all"]) + 4 * slot * self.ln_nblk_cap * 2 * d
+        return dict(mode=2, gamma=self.fp.p_ptr(gname + ".weight"), x=ptr(x), stats=ptr(stats), out=ptr(dx),
+                    out2=ptr(dx_drop) if dx_drop is not None else 0, partial=lp, d1=d1, d2=d2, _name=gname, _slot=slot, _nblk=nblk)
+
+    def _ln_b_finish(self, spec):
+        if spec["_slot"] is not None:
+            return
+        d, gname, lp, nblk = self.cfg.d_model, spec["_name"], spec["partial"], spec["_nblk"]
+        if self.fp.offsets[gname + ".bias"] == self.fp.offsets[gname + ".weight"] + d:
+            call("eg_reduce_partials", lp, self.fp.g_ptr(gname + ".weight"), 2 * d, nblk, 2 * d, 0, self.stream)
+        else:
+            call("eg_reduce_partials", lp, self.fp.g_ptr(gname + ".weight"), d, nblk, 2 * d, 0, self.stream)
+            call("eg_reduce_partials", lp + 4 * d, self.fp.g_ptr(gname + ".bias"), d, nblk, 2 * d, 0, self.stream)
+
     def ln_fwd(self, x, gname, y, stats):
         call("eg_layernorm_fwd", ptr(x), self.fp.p_ptr(gname + ".weight"), self.fp.p_ptr(gname + ".bias"), ptr(y),
              ptr(stats), self.M, self.cfg.d_model, self.dtype, self.stream)
@@ -459,7 +504,7 @@ class Engine:
         """slot: index into the deferred gain/bias partial buffer (reduced by the grouped reduce at the end of backward)"""
         d = self.cfg.d_model
         nblk = self.LN_BLOCKS
-        lp = ptr(self.g["lnpart"]) if slot is None else ptr(self.g["lnpart_all"]) + 4 * slot * nblk * 2 * d
+        lp = ptr(self.g["lnpart"]) if slot is None else ptr(self.g["lnpart_all"]) + 4 * slot * self.ln_nblk_cap * 2 * d
         call("eg_layernorm_bwd", ptr(dy), ptr(x), ptr(stats), self.fp.p_ptr(gname + ".weight"), ptr(dx), ptr(dx_drop),
              lp, nblk, self.M, d, self.dtype, d1[0], d1[1], d2[0], d2[1], self.st_ptr, self.stream)
         if slot is not None:
@@ -579,13 +624,16 @@ class Engine:
                  sites["attn"], self.st_ptr, st)
             self._probs_hook(self.model.encoder.layers[l].mha.dropout, a[f"qkv{l}"], a[f"lse{l}"], 0)
             self.gemm(ptr(a[f"ctx{l}"]), ptr(w[f"o{l}"]), ptr(a[f"r1_{l}"]), M, d, d, bias=fp.p_ptr(pre + "mha.out_proj.bias"),
-                      drop1=(p, sites["drop1"]), residual=ptr(x))
-            self.ln_fwd(a[f"r1_{l}"], pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"])
+                      drop1=(p, sites["drop1"]), residual=ptr(x), ln=self._ln_f(pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"]))
+            if not self.fuse_ln:
+                self.ln_fwd(a[f"r1_{l}"], pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"])
             self.gemm(ptr(a[f"y1_{l}"]), ptr(w[f"w1{l}"]), ptr(a[f"hff{l}"]), M, F, d, bias=fp.p_ptr(pre + "ffn.linear1.bias"),
                       act=L.ACT_RELU, drop1=(p, sites["ffn_a"]))
             self.gemm(ptr(a[f"hff{l}"]), ptr(w[f"w2{l}"]), ptr(a[f"r2_{l}"]), M, d, F, bias=fp.p_ptr(pre + "ffn.linear2.bias"),
-                      drop1=(p, sites["ffn_b"]), drop2=(p, sites["drop2"]), residual=ptr(a[f"y1_{l}"]))
-            self.ln_fwd(a[f"r2_{l}"], pre + "ln2", a[f"x{l + 1}"], a[f"st2_{l}"])
+                      drop1=(p, sites["ffn_b"]), drop2=(p, sites["drop2"]), residual=ptr(a[f"y1_{l}"]),
+                      ln=self._ln_f(pre + "ln2", a[f"x{l + 1}"], a[f"st2_{l}"]))
+            if not self.fuse_ln:
+                self.ln_fwd(a[f"r2_{l}"], pre + "ln2", a[f"x{l + 1}"], a[f"st2_{l}"])
         Lr = cfg.num_layers
         self.ln_fwd(a[f"x{Lr}"], "encoder.norm", a["zn"], a["stf"])
         z = a["zn"]
@@ -597,9 +645,10 @@ class Engine:
                  self.st_ptr, st)
             self._probs_hook(self.model.cross_attn.cross_attn.dropout, a["qkvx"], a["lsex"], B)
             self.gemm(ptr(a["ctxx"]), ptr(w["ox"]), ptr(a["rx"]), M, d, d, bias=fp.p_ptr("cross_attn.cross_attn.out_proj.bias"),
-                      drop1=(p, xs["drop1"]), residual=ptr(z))
-            call("eg_layernorm_fwd", ptr(a["rx"]), fp.p_ptr("cross_attn.norm.weight"), fp.p_ptr("cross_attn.norm.bias"),
-                 ptr(a["zc"]), ptr(a["stx"]), M, d, self.dtype, st)
+                      drop1=(p, xs["drop1"]), residual=ptr(z), ln=self._ln_f("cross_attn.norm", a["zc"], a["stx"]))
+            if not self.fuse_ln:
+                call("eg_layernorm_fwd", ptr(a["rx"]), fp.p_ptr("cross_attn.norm.weight"), fp.p_ptr("cross_attn.norm.bias"),
+                     ptr(a["zc"]), ptr(a["stx"]), M, d, self.dtype, st)
             z = a["zc"]
         self.z_final = z
         # heads (D:1193-1213)
@@ -667,8 +716,10 @@ class Engine:
 
         grouped = self._wgrad_group_plan() is not None
 
-        def attn_block_bwd(pre, l, x_in, dr, drm, kv_shift, site_attn, dx_out, dqkv, defer):
-            """dr: grad of the pre-LN sum (residual path), drm: same, masked by the branch dropout."""
+        def attn_block_bwd(pre, l, x_in, dr, drm, kv_shift, site_attn, dx_out, dqkv, defer, ln_next=None):
+            """dr: grad of the pre-LN sum (residual path), drm: same, masked by the branch dropout.
+            ln_next: LayerNorm-backward spec of the layer BELOW, applied to this block's input gradient in the epilogue of
+            the q|k|v backward-data product (then dx_out is not materialised)."""
             names = [pre + n for n in ("q_proj", "k_proj", "v_proj")]
             if not defer:
                 self.wgrad(ptr(drm), ptr(a[f"ctx{l}"]), 0, M, d, d, linear=[pre + "out_proj"])
@@ -677,7 +728,9 @@ class Engine:
                  NB, S, H, kv_shift, self.dtype, p, site_attn, self.st_ptr, st)
             if not defer:
                 self.wgrad(ptr(dqkv), ptr(x_in), 0, M, 3 * d, d, linear=names)
-            self.gemm(ptr(dqkv), ptr(w[f"qkvT{l}"]), ptr(dx_out), M, d, 3 * d, residual=ptr(dr))
+            self.gemm(ptr(dqkv), ptr(w[f"qkvT{l}"]), 0 if ln_next else ptr(dx_out), M, d, 3 * d, residual=ptr(dr), ln=ln_next)
+            if ln_next:
+                self._ln_b_finish(ln_next)
 
         has_drop = p > 0
         if cfg.use_cross_attention:
@@ -700,26 +753,41 @@ class Engine:
             dqkv = g[f"dqkv{l}"] if grouped else g["dqkv"]
             s2 = self._ln_slot[pre + "ln2"] if grouped else None
             s1 = self._ln_slot[pre + "ln1"] if grouped else None
-            if has_drop:
-                self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", g["dr"], dYf, d1=(p, sites["ffn_b"]), d2=(p, sites["drop2"]),
-                            slot=s2)
-                dr = g["dr"]
-            else:
-                self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", dYf, None, slot=s2)
-                dr = dYf
+            fuse = self.fuse_ln
+            if not (fuse and l < Lr - 1):      # (fused case: done by the layer above, in its q|k|v backward-data epilogue)
+                if has_drop:
+                    self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", g["dr"], dYf, d1=(p, sites["ffn_b"]),
+                                d2=(p, sites["drop2"]), slot=s2)
+                else:
+                    self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", dYf, None, slot=s2)
+            dr = g["dr"] if has_drop else dYf
             if not grouped:
                 self.wgrad(ptr(dYf), ptr(a[f"hff{l}"]), 0, M, d, F, linear=[pre + "ffn.linear2"])
             self.gemm(ptr(dYf), ptr(w[f"w2T{l}"]), ptr(dh), M, F, d, gate=ptr(a[f"hff{l}"]), gate_scale=sc)
             if not grouped:
                 self.wgrad(ptr(dh), ptr(a[f"y1_{l}"]), 0, M, F, d, linear=[pre + "ffn.linear1"])
-            self.gemm(ptr(dh), ptr(w[f"w1T{l}"]), ptr(g["dy1"]), M, d, F, residual=ptr(dr))
-            if has_drop:
-                self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", g["dr"], dYo, d1=(p, sites["drop1"]), slot=s1)
-                dr = g["dr"]
+            if fuse:
+                # FFN-1 backward-data + residual gradient, with ln1's backward in the epilogue (dy1 is never written)
+                spec = (self._ln_b(pre + "ln1", a[f"r1_{l}"], a[f"st1_{l}"], g["dr"], dYo, d1=(p, sites["drop1"]), slot=s1)
+                        if has_drop else self._ln_b(pre + "ln1", a[f"r1_{l}"], a[f"st1_{l}"], dYo, None, slot=s1))
+                self.gemm(ptr(dh), ptr(w[f"w1T{l}"]), 0, M, d, F, residual=ptr(dr), ln=spec)
+                self._ln_b_finish(spec)
             else:
-                self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", dYo, None, slot=s1)
-                dr = dYo
-            attn_block_bwd(pre + "mha.", l, a[f"x{l}"], dr, dYo, 0, sites["attn"], other, dqkv, grouped)
+                self.gemm(ptr(dh), ptr(w[f"w1T{l}"]), ptr(g["dy1"]), M, d, F, residual=ptr(dr))
+                if has_drop:
+                    self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", g["dr"], dYo, d1=(p, sites["drop1"]), slot=s1)
+                else:
+                    self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", dYo, None, slot=s1)
+            dr = g["dr"] if has_drop else dYo
+            ln_next = None
+            if fuse and l > 0:
+                pl, sl = f"encoder.layers.{l - 1}.", _layer_sites(l - 1)
+                dYf_n = g[f"dYf{l - 1}"] if grouped else (g["drm"] if has_drop else g["dr"])
+                sn = self._ln_slot[pl + "ln2"] if grouped else None
+                ln_next = (self._ln_b(pl + "ln2", a[f"r2_{l - 1}"], a[f"st2_{l - 1}"], g["dr"], dYf_n, d1=(p, sl["ffn_b"]),
+                                      d2=(p, sl["drop2"]), slot=sn)
+                           if has_drop else self._ln_b(pl + "ln2", a[f"r2_{l - 1}"], a[f"st2_{l - 1}"], dYf_n, None, slot=sn))
+            attn_block_bwd(pre + "mha.", l, a[f"x{l}"], dr, dYo, 0, sites["attn"], other, dqkv, grouped, ln_next)
             dz, other = other, dz
             if not grouped:
                 seg(f"layer{l}")

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define EG_ABI_VERSION 1
+#define EG_ABI_VERSION 2
 enum { EG_F32 = 0, EG_BF16 = 1 };
 enum { EG_ACT_NONE = 0, EG_ACT_RELU = 1, EG_ACT_GELU = 2 };
 
@@ -123,6 +123,23 @@ typedef struct eg_gemm_desc {
   float gate_scale; /* 1/(1-p) of the dropout that followed the gated ReLU in the forward pass, else 1 */
   int32_t a_seg_len;    /* 0, or: an A row is K/a_seg_len segments of a_seg_len contiguous elements ... */
   int64_t a_seg_stride; /* ... a_seg_stride elements apart (rows of a 2-D convolution window, D:74) */
+  /* Row-complete tile (N == 256 only): a workgroup owns whole output rows, so the LayerNorm(eps 1e-5) next to the product
+   * runs in the epilogue (A:293,295 and their backward).  row_tile != 0 selects the tile without a LayerNorm.
+   *   ln_mode 1 (forward):  C = v (the epilogue value above, required); ln_out[M,256] = LN(v as stored)*gamma+beta;
+   *                         ln_stats[M,2] = (mean, rstd)
+   *   ln_mode 2 (backward): dy = v (C optional); against the saved rows ln_x[M,256] and ln_stats: ln_out = dx,
+   *                         ln_out2 = ln_drop2(ln_drop1(dx)) or NULL, ln_partial[ceil(M/64)][2][256] = per-workgroup
+   *                         (sum_m dy*xhat | sum_m dy), to be summed in block order (eg_reduce_partials / eg_reduce_table) */
+  int32_t ln_mode, row_tile;
+  const float* ln_gamma;
+  const float* ln_beta;
+  const void* ln_x;
+  float* ln_stats;
+  void* ln_out;
+  void* ln_out2;
+  float* ln_partial;
+  float ln_drop1_p, ln_drop2_p;
+  uint32_t ln_drop1_site, ln_drop2_site;
 } eg_gemm_desc;
 int eg_gemm_nt(const eg_gemm_desc* d, void* stream);
 

@@ -7,7 +7,7 @@ from eyegaze_multimodal_amd import _lib as L
 from eyegaze_multimodal_amd._lib import GemmDesc, GemmTNDesc, call, ptr, rowmap
 dev = "cuda"
 
-def bench_nt(M, N, K, residual=False, bias=True, act=0, reps=30, dtype=L.EG_BF16):
+def bench_nt(M, N, K, residual=False, bias=True, act=0, reps=30, dtype=L.EG_BF16, row_tile=0, ln=0):
     td = torch.bfloat16 if dtype == L.EG_BF16 else torch.float32
     A = torch.randn(M, K, device=dev).to(td); W = torch.randn(N, K, device=dev).to(td); Cc = torch.zeros(M, N, device=dev, dtype=td)
     b = torch.randn(N, device=dev); R = torch.randn(M, N, device=dev).to(td)
@@ -15,6 +15,10 @@ def bench_nt(M, N, K, residual=False, bias=True, act=0, reps=30, dtype=L.EG_BF16
     d.bias = ptr(b) if bias else None; d.residual = ptr(R) if residual else None
     d.a, d.c = rowmap(K), rowmap(N); d.r = d.c; d.p = d.c
     d.M, d.N, d.K, d.ldw, d.act, d.dtype = M, N, K, K, act, dtype
+    d.row_tile = row_tile
+    if ln:
+        gm = torch.ones(N, device=dev); Y = torch.zeros(M, N, device=dev, dtype=td); S = torch.zeros(M, 2, device=dev)
+        d.ln_mode, d.ln_gamma, d.ln_beta, d.ln_out, d.ln_stats = 1, ptr(gm), ptr(gm), ptr(Y), ptr(S)
     for _ in range(5): call("eg_gemm_nt", C.byref(d), 0)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -24,8 +28,14 @@ def bench_nt(M, N, K, residual=False, bias=True, act=0, reps=30, dtype=L.EG_BF16
     us = e0.elapsed_time(e1) * 1e3 / reps
     es = 2 if dtype == L.EG_BF16 else 4
     byt = (M * K + M * N * (2 if residual else 1)) * es
-    print(f"NT M={M:6d} N={N:5d} K={K:5d} res={int(residual)} : {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TF/s  {byt/us/1e6:6.2f} TB/s  blocks={((M+127)//128)*((N+127)//128)}")
+    print(f"NT row={row_tile} ln={ln} M={M:6d} N={N:5d} K={K:5d} res={int(residual)} : {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TF/s  {byt/us/1e6:6.2f} TB/s  blocks={((M+127)//128)*((N+127)//128)}")
 
+print("-- row-complete tile vs 128x128 tile, N=256 --")
+for K in (256, 768, 1024):
+    bench_nt(33280, 256, K, residual=True)
+    bench_nt(33280, 256, K, residual=True, row_tile=1)
+    bench_nt(33280, 256, K, residual=True, ln=1)
+import sys; sys.exit(0)
 print("-- fixed cost vs per-iteration cost (N=256, plain epilogue) --")
 for M in (128, 2048, 16640, 33280):
     for K in (128, 256, 512, 1024):
