@@ -106,6 +106,7 @@ SIGNATURES = {
     "eg_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P],
     "eg_fill_f32": [_P, _L, _F, _P],
     "eg_fuzzy_gate_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P],
+    "eg_fuzzy_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P],
     "eg_ibs_analytic": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P, _P, _I, _P],
     "eg_ibs_pairs": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _I, _P],
     "eg_ibs_scalar": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _I, _I, _I, _I, _P],

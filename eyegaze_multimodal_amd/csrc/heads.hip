@@ -333,6 +333,133 @@ __global__ void fuzzy_gate_fwd_kernel(const float* __restrict__ zi, const float*
   for (int c = 0; c < K; ++c) fused[(size_t)b * K + c] = al * a[c] + (1.f - al) * e[c];
 }
 
+// FuzzyGatingFusion backward: given d fused [B,K] and (optionally) d alpha [B], the gradients of both logit sets and of the
+// 12 scalar parameters.  One thread per sample recomputes the forward (12 scalars, K <= 16 logits) and applies the chain rule
+// by hand; parameter gradients are reduced over the block into partial[blockIdx][12] (summed in block order by the caller).
+//   clamp(): torch passes the gradient where min <= x <= max (inclusive), as does this kernel.
+__device__ __forceinline__ void entropy_bwd_k(const float* z, int K, float eps_log, float dH, float* dz) {
+  // H = -sum p log(p + eps); dH/dp_c = -(log(p_c + eps) + p_c / (p_c + eps)); soft-max: dz_j = p_j (g_j - sum_c p_c g_c)
+  float mx = -INFINITY, se = 0.f;
+  for (int c = 0; c < K; ++c) mx = fmaxf(mx, z[c]);
+  for (int c = 0; c < K; ++c) se += expf(z[c] - mx);
+  float pg = 0.f;
+  for (int c = 0; c < K; ++c) {
+    const float p = expf(z[c] - mx) / se;
+    pg += p * (-(logf(p + eps_log) + p / (p + eps_log)));
+  }
+  for (int c = 0; c < K; ++c) {
+    const float p = expf(z[c] - mx) / se;
+    const float g = -(logf(p + eps_log) + p / (p + eps_log));
+    dz[c] += dH * p * (g - pg);
+  }
+}
+
+__global__ __launch_bounds__(128) void fuzzy_gate_bwd_kernel(const float* __restrict__ zi, const float* __restrict__ ze,
+                                                             const float* __restrict__ prm, const float* __restrict__ dfused,
+                                                             const float* __restrict__ dalpha, float* __restrict__ dzi,
+                                                             float* __restrict__ dze, float* __restrict__ partial, int B, int K,
+                                                             int mode, float eps_temp, float eps_log, float eps_div) {
+  __shared__ float red[2][12];
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  float dp[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) dp[i] = 0.f;
+  if (b < B) {
+    float a[16], e[16], da[16], de[16];
+    float ti = 1.f, te = 1.f;
+    const bool temp = (mode == 0 || mode == 2);
+    if (temp) { ti = softplus_f(prm[0]) + eps_temp; te = softplus_f(prm[1]) + eps_temp; }
+    for (int c = 0; c < K; ++c) { a[c] = zi[(size_t)b * K + c] / ti; e[c] = ze[(size_t)b * K + c] / te; }
+    const float Hi = entropy_k(a, K, eps_log), He = entropy_k(e, K, eps_log);
+    // ---- forward pieces needed again ----
+    float al_pre = 0.5f;
+    float ir = 0.f, iu = 0.f, er = 0.f, eu = 0.f, num = 0.f, den = 0.f, th[4] = {0.f, 0.f, 0.f, 0.f};
+    float ci = 0.f, ce = 0.f, ci_raw = 0.f, ce_raw = 0.f;
+    auto D_of = [&](float ls) { const float s = expf(ls); return 2.f * s * s + eps_div; };
+    if (mode == 2) {
+      const float hmax = logf((float)K);
+      ci_raw = 1.0f - Hi / (hmax + eps_div); ce_raw = 1.0f - He / (hmax + eps_div);
+      ci = fmaxf(ci_raw, 0.f); ce = fmaxf(ce_raw, 0.f);
+      al_pre = ci / (ci + ce + eps_div);
+    } else if (mode != 3) {
+      ir = expf(-(Hi * Hi) / D_of(prm[4]));
+      iu = expf(-((Hi - prm[2]) * (Hi - prm[2])) / D_of(prm[6]));
+      er = expf(-(He * He) / D_of(prm[5]));
+      eu = expf(-((He - prm[3]) * (He - prm[3])) / D_of(prm[7]));
+      const float w[4] = {ir * eu, iu * er, ir * er, iu * eu};
+      for (int k = 0; k < 4; ++k) { th[k] = 1.f / (1.f + expf(-prm[8 + k])); num += w[k] * th[k]; den += w[k]; }
+      al_pre = num / (den + eps_div);
+    }
+    const float al = fminf(fmaxf(al_pre, 0.f), 1.f);
+    // ---- fusion: fused = al * a + (1 - al) * e ----
+    float dal = dalpha ? dalpha[b] : 0.f;
+    for (int c = 0; c < K; ++c) {
+      const float g = dfused[(size_t)b * K + c];
+      da[c] = al * g;
+      de[c] = (1.f - al) * g;
+      dal += g * (a[c] - e[c]);
+    }
+    if (!(al_pre >= 0.f && al_pre <= 1.f)) dal = 0.f;
+    float dHi = 0.f, dHe = 0.f;
+    if (mode == 2) {
+      const float s = ci + ce + eps_div, hmax = logf((float)K);
+      const float dci = dal * (ce + eps_div) / (s * s), dce = -dal * ci / (s * s);
+      if (ci_raw >= 0.f) dHi = -dci / (hmax + eps_div);
+      if (ce_raw >= 0.f) dHe = -dce / (hmax + eps_div);
+    } else if (mode != 3) {
+      const float dd = den + eps_div;
+      const float dnum = dal / dd, dden = -dal * num / (dd * dd);
+      const float w[4] = {ir * eu, iu * er, ir * er, iu * eu};
+      float dw[4];
+      for (int k = 0; k < 4; ++k) {
+        dw[k] = dnum * th[k] + dden;
+        dp[8 + k] = dnum * w[k] * th[k] * (1.f - th[k]);
+      }
+      const float dir = dw[0] * eu + dw[2] * er, deu = dw[0] * ir + dw[3] * iu;
+      const float diu = dw[1] * er + dw[3] * eu, der = dw[1] * iu + dw[2] * ir;
+      // mu(x; c, ls) = exp(-(x-c)^2 / D), D = 2 exp(2 ls) + eps:  d/dx = mu * (-2 (x-c) / D), d/dc = -d/dx,
+      //                                                          d/dls = mu * (x-c)^2 / D^2 * 4 exp(2 ls)
+      auto mu_bwd = [&](float x, float c, float ls, float m, float dm, float& dx, float& dc, float& dls) {
+        const float D = D_of(ls), s2 = expf(2.f * ls), t = x - c;
+        const float gx = dm * m * (-2.f * t / D);
+        dx += gx;
+        dc -= gx;
+        dls += dm * m * (t * t) / (D * D) * 4.f * s2;
+      };
+      float dummy = 0.f;
+      mu_bwd(Hi, 0.f, prm[4], ir, dir, dHi, dummy, dp[4]);
+      mu_bwd(Hi, prm[2], prm[6], iu, diu, dHi, dp[2], dp[6]);
+      mu_bwd(He, 0.f, prm[5], er, der, dHe, dummy, dp[5]);
+      mu_bwd(He, prm[3], prm[7], eu, deu, dHe, dp[3], dp[7]);
+    }
+    if (mode != 3) {
+      entropy_bwd_k(a, K, eps_log, dHi, da);
+      entropy_bwd_k(e, K, eps_log, dHe, de);
+    }
+    // ---- temperature: a = z / T, T = softplus(tau) + eps ----
+    float dTi = 0.f, dTe = 0.f;
+    for (int c = 0; c < K; ++c) {
+      dzi[(size_t)b * K + c] = da[c] / ti;
+      dze[(size_t)b * K + c] = de[c] / te;
+      dTi -= da[c] * a[c] / ti;
+      dTe -= de[c] * e[c] / te;
+    }
+    if (temp) {
+      dp[0] = dTi / (1.f + expf(-prm[0]));   // softplus' = sigmoid
+      dp[1] = dTe / (1.f + expf(-prm[1]));
+    }
+  }
+  // block reduction of the 12 parameter gradients (2 waves of 64)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const float v = wave_sum(dp[i]);
+    if (lane == 0) red[wv][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) partial[(size_t)blockIdx.x * 12 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x];
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL_BF16, CALL_F32, who)          \
@@ -451,6 +578,17 @@ extern "C" int eg_rows_gather_gate(const void* src, const void* gate, void* dst,
              hipLaunchKernelGGL(rows_gather_gate_kernel<float>, grid, dim3(64), 0, s, (const float*)src, (const float*)gate, (float*)dst, to_rowmap(dmap), S, D, R, off, pair_shift, gate_scale),
              "eg_rows_gather_gate");
   EG_LAUNCH_CHECK("rows_gather_gate");
+  return 0;
+}
+
+extern "C" int eg_fuzzy_gate_bwd(const float* z_img, const float* z_eeg, const float* params, const float* dfused,
+                                 const float* dalpha, float* dz_img, float* dz_eeg, float* partial, int B, int K, int mode,
+                                 float eps_temp, float eps_log, float eps_div, void* stream) {
+  EG_CHECK(z_img && z_eeg && params && dfused && dz_img && dz_eeg && partial, "eg_fuzzy_gate_bwd: null pointer");
+  EG_CHECK(B > 0 && K > 1 && K <= 16 && mode >= 0 && mode <= 3, "eg_fuzzy_gate_bwd: bad shape / mode");
+  hipLaunchKernelGGL(fuzzy_gate_bwd_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, z_img, z_eeg, params,
+                     dfused, dalpha, dz_img, dz_eeg, partial, B, K, mode, eps_temp, eps_log, eps_div);
+  EG_LAUNCH_CHECK("fuzzy_gate_bwd");
   return 0;
 }
 

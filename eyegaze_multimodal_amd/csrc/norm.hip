@@ -190,26 +190,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd256_kernel(const T* __restri
   const int nrows = gridDim.x * 8;
   // both halves of a wave must run the same trip count (the shuffles below are wave-wide)
   const int trips = (M + nrows - 1) / nrows;
+  // software pipeline: the next trip's rows are requested before this trip's arithmetic (4 x 16 B in flight per lane)
+  struct Row { float xv[8], dv[8], mean, rstd; };
+  auto fetch = [&](int it, Row& r) {
+    const int row = it * nrows + blockIdx.x * 8 + hw;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { r.xv[e] = 0.f; r.dv[e] = 0.f; }
+    r.mean = 0.f; r.rstd = 0.f;
+    if (it < trips && row < M) {
+      load8(x + (size_t)row * 256 + l * 8, r.xv);
+      load8(dy + (size_t)row * 256 + l * 8, r.dv);
+      r.mean = stats[2 * row];
+      r.rstd = stats[2 * row + 1];
+    }
+  };
+  Row cur, nxt;
+  fetch(0, cur);
   for (int it = 0; it < trips; ++it) {
+    fetch(it + 1, nxt);
     const int row = it * nrows + blockIdx.x * 8 + hw;
     const bool ok = row < M;
-    float xv[8], dv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { xv[e] = 0.f; dv[e] = 0.f; }
-    float mean = 0.f, rstd = 0.f;
-    if (ok) {
-      load8(x + (size_t)row * 256 + l * 8, xv);
-      load8(dy + (size_t)row * 256 + l * 8, dv);
-      mean = stats[2 * row];
-      rstd = stats[2 * row + 1];
-    }
+    const float mean = cur.mean, rstd = cur.rstd;
     float xh[8], s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      xh[e] = (xv[e] - mean) * rstd;
-      dg[e] += dv[e] * xh[e];
-      db[e] += dv[e];
-      const float dxh = dv[e] * g[e];
+      xh[e] = (cur.xv[e] - mean) * rstd;
+      dg[e] += cur.dv[e] * xh[e];
+      db[e] += cur.dv[e];
+      const float dxh = cur.dv[e] * g[e];
       s1 += dxh;
       s2 += dxh * xh[e];
     }
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd256_kernel(const T* __restri
     if (ok) {
       float o[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = rstd * (dv[e] * g[e] - c1 - xh[e] * c2);
+      for (int e = 0; e < 8; ++e) o[e] = rstd * (cur.dv[e] * g[e] - c1 - xh[e] * c2);
       store8(dx + (size_t)row * 256 + l * 8, o);
       if (dx_drop) {
         if (drop) {
@@ -228,6 +236,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd256_kernel(const T* __restri
         store8(dx_drop + (size_t)row * 256 + l * 8, o);
       }
     }
+    cur = nxt;
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {

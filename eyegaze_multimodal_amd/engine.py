@@ -498,7 +498,7 @@ class Engine:
         call("eg_layernorm_fwd", ptr(x), self.fp.p_ptr(gname + ".weight"), self.fp.p_ptr(gname + ".bias"), ptr(y),
              ptr(stats), self.M, self.cfg.d_model, self.dtype, self.stream)
 
-    LN_BLOCKS = 512
+    LN_BLOCKS = int(os.environ.get("EYEGAZE_LN_BLOCKS", "512"))
 
     def ln_bwd(self, dy, x, stats, gname, dx, dx_drop=None, d1=(0.0, 0), d2=(0.0, 0), slot=None):
         """slot: index into the deferred gain/bias partial buffer (reduced by the grouped reduce at the end of backward)"""

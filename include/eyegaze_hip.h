@@ -247,9 +247,15 @@ int eg_rows_gather_gate(const void* src, const void* gate, void* dst, eg_rowmap 
 /* FuzzyGatingFusion.forward — 3_Models/fusion/fuzzy_gating_fusion.py:297-390 (config 5's logit-level fusion).
  * params = [tau_img, tau_eeg, c_unreliable_img, c_unreliable_eeg, log_sigma_reliable_img, log_sigma_reliable_eeg,
  *           log_sigma_unreliable_img, log_sigma_unreliable_eeg, beta[4]] (12 device floats);
- * mode 0 full, 1 no_temperature, 2 no_fuzzification, 3 fixed_weights.  Forward only in this version. */
+ * mode 0 full, 1 no_temperature, 2 no_fuzzification, 3 fixed_weights.
+ * eg_fuzzy_gate_bwd: what autograd computes through that forward — dz_img, dz_eeg [B,K] and the 12 parameter gradients as
+ *   per-workgroup partials partial[ceil(B/128)][12] (sum them in block order with eg_reduce_partials), from dfused [B,K] and
+ *   dalpha [B] (or NULL).  torch.clamp semantics: the gradient passes where min <= x <= max. */
 int eg_fuzzy_gate_fwd(const float* z_img, const float* z_eeg, const float* params, float* fused, float* alpha, int B,
                       int K, int mode, float eps_temp, float eps_log, float eps_div, void* stream);
+int eg_fuzzy_gate_bwd(const float* z_img, const float* z_eeg, const float* params, const float* dfused, const float* dalpha,
+                      float* dz_img, float* dz_eeg, float* partial, int B, int K, int mode, float eps_temp, float eps_log,
+                      float eps_div, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimiser over flat fp32 buffers — clip_grad_norm_(1.0) + AdamW (T:221-222, T:401-405)

@@ -44,3 +44,61 @@ def fuzzy_forward(z_img, z_eeg, p, mode="full", eps_temp=0.1, eps_log=1e-8, eps_
         alpha = np.clip((w * theta).sum(-1) / (w.sum(-1) + eps_div), 0, 1)  # :256-262
     fused = alpha[:, None] * zi + (1 - alpha[:, None]) * ze    # :386-388
     return fused, alpha
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# differentiable restatement (torch fp32, autograd) used to pin gradients: tests/golden/fuzzy_grad.npz
+# ------------------------------------------------------------------------------------------------------------------
+PARAM_NAMES = ["tau_img", "tau_eeg", "c_unreliable_img", "c_unreliable_eeg", "log_sigma_reliable_img", "log_sigma_reliable_eeg",
+               "log_sigma_unreliable_img", "log_sigma_unreliable_eeg", "beta"]
+
+
+def fuzzy_forward_torch(z_img, z_eeg, p, mode="full", eps_temp=0.1, eps_log=1e-8, eps_div=1e-8):
+    """Same math as fuzzy_forward on torch tensors (p: name -> tensor, may require grad).  Returns fused, alpha, (T_img, T_eeg)."""
+    import torch
+    import torch.nn.functional as F
+    K = z_img.shape[1]
+    if mode in ("no_temperature", "fixed_weights"):
+        Ti = Te = torch.ones(())
+        zi, ze = z_img, z_eeg
+    else:
+        Ti, Te = F.softplus(p["tau_img"]) + eps_temp, F.softplus(p["tau_eeg"]) + eps_temp
+        zi, ze = z_img / Ti, z_eeg / Te
+
+    def entropy(z):
+        pr = torch.softmax(z, -1)
+        return -(pr * torch.log(pr + eps_log)).sum(-1)
+    Hi, He = entropy(zi), entropy(ze)
+    if mode == "fixed_weights":
+        alpha = torch.full((z_img.shape[0],), 0.5)
+    elif mode == "no_fuzzification":
+        hmax = math.log(K)
+        ci = torch.clamp(1.0 - Hi / (hmax + eps_div), min=0.0)
+        ce = torch.clamp(1.0 - He / (hmax + eps_div), min=0.0)
+        alpha = torch.clamp(ci / (ci + ce + eps_div), 0.0, 1.0)
+    else:
+        def mu(x, c, ls):
+            return torch.exp(-((x - c) ** 2) / (2 * torch.exp(ls) ** 2 + eps_div))
+        ir, iu = mu(Hi, 0.0, p["log_sigma_reliable_img"]), mu(Hi, p["c_unreliable_img"], p["log_sigma_unreliable_img"])
+        er, eu = mu(He, 0.0, p["log_sigma_reliable_eeg"]), mu(He, p["c_unreliable_eeg"], p["log_sigma_unreliable_eeg"])
+        w = torch.stack([ir * eu, iu * er, ir * er, iu * eu], -1)
+        alpha = torch.clamp((w * torch.sigmoid(p["beta"])).sum(-1) / (w.sum(-1) + eps_div), 0.0, 1.0)
+    fused = alpha[:, None] * zi + (1 - alpha[:, None]) * ze
+    return fused, alpha, (Ti, Te)
+
+
+def temperature_regularization(p, t_min=0.5, t_max=5.0, eps_temp=0.1):
+    """fuzzy_gating_fusion.py:392-419"""
+    import torch.nn.functional as F
+    Ti, Te = F.softplus(p["tau_img"]) + eps_temp, F.softplus(p["tau_eeg"]) + eps_temp
+    return F.relu(Ti - t_max) + F.relu(t_min - Ti) + F.relu(Te - t_max) + F.relu(t_min - Te)
+
+
+def fusion_loop_loss(z_img, z_eeg, labels, p, mode, lam_img=0.3, lam_eeg=0.3, lam_reg=0.1, t_min=0.5, t_max=5.0):
+    """The loss of the reference's multimodal step (train_multimodal_fuzzy_fusion.py:436-460); auxiliary terms use the
+    DETACHED temperatures (aux_info['temperatures'] holds .detach()ed tensors, fuzzy_gating_fusion.py:334)."""
+    import torch.nn.functional as F
+    fused, alpha, (Ti, Te) = fuzzy_forward_torch(z_img, z_eeg, p, mode)
+    loss = (F.cross_entropy(fused, labels) + lam_img * F.cross_entropy(z_img / Ti.detach(), labels)
+            + lam_eeg * F.cross_entropy(z_eeg / Te.detach(), labels) + lam_reg * temperature_regularization(p, t_min, t_max))
+    return loss, fused, alpha

@@ -340,3 +340,39 @@ def test_fused_layernorm_epilogue_path(name, monkeypatch):
     ga, gb = grads["1"][1].double(), grads["0"][1].double()
     cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
     assert cos > 0.995 and abs(float(ga.norm() / gb.norm()) - 1) < 0.03, (cos, float(ga.norm()), float(gb.norm()))
+
+
+def test_multimodal_fusion_step_reaches_the_hip_backward():
+    """Config 5's logit-level fusion step (train_multimodal_fuzzy_fusion.py:432-470) around the HIP EEG model: the gradient
+    of the fused loss w.r.t. the EEG logits must enter the HIP backward.  The image branch is a stand-in (fixed logits; the
+    reference's ViT needs timm + downloaded weights, absent here).  Check: classifier.3.bias.grad == column sums of the
+    oracle's d loss / d eeg_logits evaluated at the model's own logits."""
+    import torch.nn.functional as F
+    from eyegaze_multimodal_amd.fuzzy_gating_fusion import FuzzyGatingFusion
+    from oracle import fuzzy_oracle as FO
+    z, kw, cfg, sd, model = build("cfg3_xattn", "f32")
+    model.eval()
+    x1, x2, labels = t(z["gen_eeg/eeg1"]).to(DEV), t(z["gen_eeg/eeg2"]).to(DEV), t(z["labels"]).to(DEV)
+    fusion = FuzzyGatingFusion(num_classes=3, mode="full").to(DEV)
+    img_logits = torch.tensor([[2.0, -1.0, 0.5], [0.1, 0.0, -0.1], [-1.0, 3.0, 0.0], [0.3, 0.2, 0.1]], device=DEV, requires_grad=True)
+    out = model(x1, x2)
+    fused, alpha, aux = fusion(img_logits, out["logits"])
+    T_i, T_e = aux["temperatures"]["img"], aux["temperatures"]["eeg"]
+    loss = (F.cross_entropy(fused, labels) + 0.3 * F.cross_entropy(img_logits / T_i, labels)
+            + 0.3 * F.cross_entropy(out["logits"] / T_e, labels) + 0.1 * fusion.compute_temperature_regularization())
+    loss.backward()
+    torch.cuda.synchronize()
+    # oracle on CPU at the same logits
+    p = {n: v.detach().cpu().clone().requires_grad_(True) for n, v in fusion.named_parameters()}
+    zi = img_logits.detach().cpu().clone().requires_grad_(True)
+    ze = out["logits"].detach().cpu().clone().requires_grad_(True)
+    ref_loss, _, _ = FO.fusion_loop_loss(zi, ze, labels.cpu(), p, "full")
+    ref_loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 1e-5
+    np.testing.assert_allclose(img_logits.grad.cpu().numpy(), zi.grad.numpy(), atol=2e-6)
+    got = dict(model.named_parameters())["classifier.3.bias"].grad.cpu().numpy()
+    np.testing.assert_allclose(got, ze.grad.sum(0).numpy(), atol=2e-6)
+    for n, q in fusion.named_parameters():
+        np.testing.assert_allclose(q.grad.cpu().numpy(), p[n].grad.numpy(), atol=2e-6, err_msg=n)
+    # and the encoder received it too
+    assert float(dict(model.named_parameters())["encoder.layers.0.mha.q_proj.weight"].grad.abs().sum()) > 0

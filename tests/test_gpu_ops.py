@@ -440,12 +440,73 @@ def test_fuzzy_gating_fusion_matches_reference(mode):
     m = FuzzyGatingFusion(num_classes=3, mode=mode)
     sd = {k.split("/state/")[1]: torch.from_numpy(z[k]) for k in z.files if k.startswith(mode + "/state/")}
     m.load_state_dict(sd, strict=True)
-    fused, alpha, _ = m(torch.from_numpy(z["z_img"]).to(DEV), torch.from_numpy(z["z_eeg"]).to(DEV))
+    with torch.no_grad():
+        fused, alpha, _ = m.to(DEV)(torch.from_numpy(z["z_img"]).to(DEV), torch.from_numpy(z["z_eeg"]).to(DEV))
     torch.cuda.synchronize()
     np.testing.assert_allclose(fused.cpu().numpy(), z[mode + "/z_fused"], atol=2e-5)
     # sample 0 of no_fuzzification is 0/0 in fp32 (both entropies at their maximum): skip its alpha
     sl = slice(1, None) if mode == "no_fuzzification" else slice(None)
     np.testing.assert_allclose(alpha.cpu().numpy()[sl], z[mode + "/alpha"][sl], atol=2e-5)
+
+
+@pytest.mark.parametrize("mode", ["full", "no_temperature", "no_fuzzification", "fixed_weights"])
+@pytest.mark.parametrize("variant", ["generic", "loop"])
+def test_fuzzy_gating_fusion_gradients_match_reference(mode, variant):
+    """eg_fuzzy_gate_bwd behind autograd against gradients the reference module produced under torch autograd
+    (tests/golden/fuzzy_grad.npz): a generic upstream gradient (CE on fused + a term in alpha) and the loss of the
+    reference's multimodal step (train_multimodal_fuzzy_fusion.py:436-460)."""
+    import torch.nn.functional as F
+    from eyegaze_multimodal_amd.fuzzy_gating_fusion import FuzzyGatingFusion
+    from tests.helpers import GOLDEN
+    z = np.load(GOLDEN / "fuzzy_grad.npz")
+    m = FuzzyGatingFusion(num_classes=3, mode=mode)
+    m.load_state_dict({k.split("/state/")[1]: torch.from_numpy(z[k]) for k in z.files if k.startswith(mode + "/state/")}, strict=True)
+    m = m.to(DEV)
+    zi = torch.from_numpy(z["z_img"]).to(DEV).requires_grad_(True)
+    ze = torch.from_numpy(z["z_eeg"]).to(DEV).requires_grad_(True)
+    labels = torch.from_numpy(z["labels"]).to(DEV)
+    fused, alpha, aux = m(zi, ze)
+    if variant == "generic":
+        loss = F.cross_entropy(fused, labels) + 0.3 * (alpha ** 2).sum()
+    else:
+        T_i, T_e = aux["temperatures"]["img"], aux["temperatures"]["eeg"]
+        loss = (F.cross_entropy(fused, labels) + 0.3 * F.cross_entropy(zi / T_i, labels) + 0.3 * F.cross_entropy(ze / T_e, labels)
+                + 0.1 * m.compute_temperature_regularization(0.5, 5.0))
+    loss.backward()
+    torch.cuda.synchronize()
+    pre = f"{mode}/{variant}/"
+    np.testing.assert_allclose(fused.detach().cpu().numpy(), z[pre + "fused"], atol=2e-5)
+    np.testing.assert_allclose(alpha.detach().cpu().numpy(), z[pre + "alpha"], atol=1e-5)
+    np.testing.assert_allclose(float(loss), float(z[pre + "loss"]), atol=2e-5)
+    np.testing.assert_allclose(zi.grad.cpu().numpy(), z[pre + "d_img"], atol=5e-6, rtol=1e-4)
+    np.testing.assert_allclose(ze.grad.cpu().numpy(), z[pre + "d_eeg"], atol=5e-6, rtol=1e-4)
+    for n, p in m.named_parameters():
+        got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(z[pre + "d_" + n])
+        np.testing.assert_allclose(got, z[pre + "d_" + n], atol=1e-5, rtol=2e-4, err_msg=n)
+
+
+def test_fuzzy_gating_fusion_large_batch_reduction():
+    """B > one workgroup: the 12 parameter gradients are block partials summed in order; compare with the CPU oracle."""
+    import torch.nn.functional as F
+    from eyegaze_multimodal_amd.fuzzy_gating_fusion import FuzzyGatingFusion
+    from oracle import fuzzy_oracle as FO
+    g = torch.Generator().manual_seed(3)
+    B = 1000
+    zi, ze = torch.randn(B, 3, generator=g) * 2, torch.randn(B, 3, generator=g) * 2
+    labels = torch.arange(B) % 3
+    m = FuzzyGatingFusion(num_classes=3, mode="full")
+    p = {n: v.detach().clone().requires_grad_(True) for n, v in m.named_parameters()}
+    a, b = zi.clone().requires_grad_(True), ze.clone().requires_grad_(True)
+    fused, alpha, _ = FO.fuzzy_forward_torch(a, b, p, "full")
+    F.cross_entropy(fused, labels).backward()
+    m = m.to(DEV)
+    zd, ed = zi.to(DEV).requires_grad_(True), ze.to(DEV).requires_grad_(True)
+    out = m(zd, ed)
+    F.cross_entropy(out[0], labels.to(DEV)).backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(zd.grad.cpu().numpy(), a.grad.numpy(), atol=2e-7, rtol=1e-3)
+    for n, q in m.named_parameters():
+        np.testing.assert_allclose(q.grad.cpu().numpy(), p[n].grad.numpy(), atol=2e-6, rtol=1e-3, err_msg=n)
 
 
 # ------------------------------------------------------------------------------------------------
