@@ -97,26 +97,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (kt < nkt) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf, s[kt], 0, 0, 0);
+      if (kt < nkt) {   // wave-uniform: key tiles beyond the sequence cost nothing (S = 65 uses 5 of the 6 tiles)
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf, s[kt], 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * g + r;
-        const float v = key < S ? s[kt][r] * kScale : -INFINITY;
-        s[kt][r] = v;
-        mx = fmaxf(mx, v);
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * g + r;
+          const float v = key < S ? s[kt][r] * kScale : -INFINITY;
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt < nkt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __expf(s[kt][r] - mx);
-        s[kt][r] = p;
-        sum += p;
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(s[kt][r] - mx);
+          s[kt][r] = p;
+          sum += p;
+        }
       }
+    }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
@@ -124,12 +129,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const uint32_t rowidx = (uint32_t)((b * H + h) * S + q) * (uint32_t)((S + 1) & ~1);  // even row pitch: aligned pairs
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      float pv[4];
+      if (kt < nkt) {
+        float pv[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pv[r] = s[kt][r] * inv;
-      eg_dropout_run<4>(pv, dc, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g));
+        for (int r = 0; r < 4; ++r) pv[r] = s[kt][r] * inv;
+        eg_dropout_run<4>(pv, dc, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g));
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s[kt][r] = pv[r];
+        for (int r = 0; r < 4; ++r) s[kt][r] = pv[r];
+      }
     }
     f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll

@@ -364,7 +364,8 @@ class Engine:
                                        self.fp.offsets[n + ".bias"] == base + i * (P * K + P) + P * K
                                        for i, n in enumerate(linear))
         slab = N * K + (N if fused else 0)
-        splits = max(1, min((M + 127) // 128, (768 + tiles - 1) // tiles, self.tn_cap // slab))
+        # one resident round: 256 CUs x 3 workgroups; rounding the split count UP would leave a nearly empty second round
+        splits = max(1, min((M + 127) // 128, max(1, 768 // tiles), self.tn_cap // slab))
         dsc = GemmTNDesc()
         dsc.dY, dsc.X, dsc.partial = dY, X, ptr(self.g["partial"])
         dsc.y = y or rowmap(N)
