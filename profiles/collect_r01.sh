@@ -13,5 +13,5 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3
 python profiles/tools/pmc_summary.py $O/pmc_fetch $O/pmc_write gemm_nt_kernel $O/pmc_gemm_nt.json
 python profiles/tools/kernel_summary.py $O/trace 121 > $O/kernel_summary.txt
 cp $(find $O/trace -name '*kernel_stats.csv' | head -n1) $O/kernel_stats.csv
-rm -rf $O/trace/*/*kernel_trace.csv $O/pmc_fetch $O/pmc_write   # raw traces are large; the summaries above are what gets committed
+rm -rf $O/trace/*kernel_trace.csv $O/pmc_fetch $O/pmc_write   # raw traces are large; the summaries above are what gets committed
 tail -n 3 $O/kernel_summary.txt
