@@ -30,22 +30,29 @@ def bench_nt(M, N, K, residual=False, bias=True, act=0, reps=30, dtype=L.EG_BF16
     byt = (M * K + M * N * (2 if residual else 1)) * es
     print(f"NT row={row_tile} ln={ln} M={M:6d} N={N:5d} K={K:5d} res={int(residual)} : {us:8.1f} us  {2*M*N*K/us/1e6:7.1f} TF/s  {byt/us/1e6:6.2f} TB/s  blocks={((M+127)//128)*((N+127)//128)}")
 
-print("-- row-complete tile vs 128x128 tile, N=256 --")
-for K in (256, 768, 1024):
-    bench_nt(33280, 256, K, residual=True)
-    bench_nt(33280, 256, K, residual=True, row_tile=1)
-    bench_nt(33280, 256, K, residual=True, ln=1)
-import sys; sys.exit(0)
-print("-- fixed cost vs per-iteration cost (N=256, plain epilogue) --")
-for M in (128, 2048, 16640, 33280):
-    for K in (128, 256, 512, 1024):
-        bench_nt(M, 256, K, residual=False, bias=True)
-print("-- epilogue variants at M=33280 N=256 K=256 --")
-bench_nt(33280, 256, 256, residual=False, bias=False)
-bench_nt(33280, 256, 256, residual=True, bias=True)
-print("-- N scaling at K=256 --")
-for N in (128, 256, 512, 768, 1024):
-    bench_nt(33280, N, 256)
-print("-- misc --")
-bench_nt(32768, 256, 6400)
-bench_nt(8192, 8192, 8192)
+SECTIONS = sys.argv[1:] or ["rounds", "rowtile", "fixed", "nscale"]
+
+if "rounds" in SECTIONS:
+    print("-- round quantisation: N=1024 K=256, 768 resident workgroups (256 CUs x 3) --")
+    for mt in (48, 96, 97, 144, 192, 193, 260, 288):
+        bench_nt(mt * 128, 1024, 256, act=1)
+    print("-- same, N=256 --")
+    for mt in (96, 192, 260, 384, 385, 520):
+        bench_nt(mt * 128, 256, 256, residual=True)
+if "rowtile" in SECTIONS:
+    print("-- row-complete tile vs 128x128 tile, N=256 --")
+    for K in (256, 768, 1024):
+        bench_nt(33280, 256, K, residual=True)
+        bench_nt(33280, 256, K, residual=True, row_tile=1)
+        bench_nt(33280, 256, K, residual=True, ln=1)
+if "fixed" in SECTIONS:
+    print("-- fixed cost vs per-iteration cost (N=256, plain epilogue) --")
+    for M in (128, 2048, 16640, 33280):
+        for K in (128, 256, 512, 1024):
+            bench_nt(M, 256, K, residual=False, bias=True)
+if "nscale" in SECTIONS:
+    print("-- N scaling at K=256 --")
+    for N in (128, 256, 512, 768, 1024):
+        bench_nt(33280, N, 256)
+    bench_nt(32768, 256, 6400)
+    bench_nt(8192, 8192, 8192)
