@@ -106,10 +106,17 @@ __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
 // hash count matters (the hash is ~60 % of the attention backward's VALU time).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t eg_hash(uint32_t seed_lo, uint32_t seed_hi, uint32_t site, uint32_t idx) {
-  // "lowbias32" finalizer (two multiplies) with the seed's high word folded in between the rounds
-  uint32_t x = idx ^ (site * 0x9E3779B9u) ^ seed_lo;
+  // Per-site words (wave-uniform: scalar ALU, hoisted out of the element loops): every dropout site of a step gets its own
+  // pair (a, b), so two sites -- or two steps, the host passes a scrambled 64-bit seed (engine.scramble_seed) -- are never
+  // XOR-permutations or constant offsets of one fixed pattern (with a plain `idx ^ site ^ seed` every row kept the same
+  // NUMBER of elements at every step).
+  const uint32_t k = site * 0x9E3779B9u;
+  uint32_t a = (seed_lo ^ k) * 0x85EBCA6Bu; a ^= a >> 15;
+  uint32_t b = (seed_hi + k) * 0xC2B2AE35u; b ^= b >> 13;
+  // per element: "lowbias32" finalizer (two multiplies) with b folded in between the rounds
+  uint32_t x = idx ^ a;
   x ^= x >> 16; x *= 0x7FEB352Du;
-  x ^= x >> 15; x += seed_hi;
+  x ^= x >> 15; x += b;
   x *= 0x846CA68Bu; x ^= x >> 16;
   return x;
 }

@@ -26,6 +26,15 @@ from ._lib import EG_BF16, EG_F32, GemmDesc, GemmTNDesc, StepState, call, ptr, r
 SITE_CONV0, SITE_CONV1, SITE_SPEC, SITE_IBSTOK, SITE_IBSGEN, SITE_CLS, SITE_IBSCLS = 1, 2, 3, 4, 5, 6, 7
 
 
+def scramble_seed(seed: int) -> int:
+    """splitmix64 finalizer: the 64-bit word whose halves eg_step_state.seed_lo / seed_hi carry to the dropout hash."""
+    m = (1 << 64) - 1
+    z = (seed + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
+
+
 def _layer_sites(l: int):
     b = 16 + 8 * l
     return dict(attn=b, drop1=b + 1, ffn_a=b + 2, ffn_b=b + 3, drop2=b + 4)
@@ -251,6 +260,7 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------
     def set_state(self, seed: int, lr: float, step: int, grad_scale: float = 1.0, beta1=0.9, beta2=0.999):
+        seed = scramble_seed(seed)     # consecutive step seeds must not share their low / high words (common.h: eg_hash)
         st = StepState(seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, lr, 1.0 - beta1 ** step, 1.0 - beta2 ** step,
                        grad_scale, 1.0, 0.0)
         C.memmove(self.state_host.data_ptr(), C.addressof(st), C.sizeof(st))

@@ -95,6 +95,22 @@ SCALAR_BANDS: List[Tuple[float, float]] = [(4, 8), (8, 13), (13, 30), (30, 45)]
 # a4  TemporalConvFrontend  (D:138-175)
 # --------------------------------------------------------------------------------------
 
+# Train-mode dropout.  By default torch's own generator (as in the reference).  Tests may install DROPOUT_OVERRIDE(t, p, site)
+# to inject masks (e.g. the HIP path's counter-hash masks, so that train mode can be compared exactly); `site` names the call:
+# ("conv", i) ("attn", prefix) ("drop1", l) ("ffn_a", l) ("ffn_b", l) ("drop2", l) ("xdrop1",) ("cls",) ("ibscls",) ("spec",)
+# ("ibstok",) ("ibsgen",), and CTX["stream"] says which of the two streams (or cross-attention directions) is being computed.
+DROPOUT_OVERRIDE = None
+CTX = {"stream": 0}
+
+
+def _dropout(t: Tensor, p: float, site) -> Tensor:
+    if p <= 0:
+        return t
+    if DROPOUT_OVERRIDE is not None:
+        return DROPOUT_OVERRIDE(t, p, site)
+    return F.dropout(t, p, True)
+
+
 def temporal_conv(x: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, p_drop: float = 0.0) -> Tensor:
     """[B,C,T] -> [B,T~,d]: (conv1d k,stride,pad=k//2 -> ReLU -> dropout(0.1 in train)) x L, then
     channel-last.  D:170-174.  p_drop=0 restates eval mode."""
@@ -104,8 +120,7 @@ def temporal_conv(x: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, p_drop: float
         b = sd[f"temporal_conv.convs.{i}.bias"]
         h = F.conv1d(h, w, b, stride=cfg.conv_stride, padding=cfg.conv_kernel_size // 2)
         h = torch.relu(h)
-        if p_drop > 0:
-            h = F.dropout(h, p_drop, True)
+        h = _dropout(h, p_drop, ("conv", i))
     return h.transpose(1, 2)
 
 
@@ -142,7 +157,7 @@ def spectrogram_tokens(x: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, p_drop: 
     h = F.adaptive_avg_pool2d(torch.relu(h), (4, 4)).flatten(1)
     h = torch.relu(F.linear(h, sd[pre + "proj.0.weight"], sd[pre + "proj.0.bias"]))
     if p_drop > 0:
-        h = F.dropout(h, p_drop, True)
+        h = _dropout(h, p_drop, ("spec",))
     tok = F.linear(h, sd[pre + "proj.3.weight"], sd[pre + "proj.3.bias"]).reshape(B, C, cfg.d_model)
     return (tok, lm) if return_logmag else tok
 
@@ -235,7 +250,7 @@ def ibs_tokenize(conn: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, p_drop: flo
         x = x * sd[pre + "instance_norm.weight"] + sd[pre + "instance_norm.bias"]
     h = F.gelu(F.linear(x, sd[pre + "bottleneck.0.weight"], sd[pre + "bottleneck.0.bias"]))
     if p_drop > 0:
-        h = F.dropout(h, p_drop, True)
+        h = _dropout(h, p_drop, ("ibstok",))
     h = F.linear(h, sd[pre + "bottleneck.3.weight"], sd[pre + "bottleneck.3.bias"])
     return h + sd[pre + "type_embedding"]
 
@@ -275,7 +290,7 @@ def ibs_scalar_token(eeg1: Tensor, eeg2: Tensor, sd: Dict[str, Tensor], cfg: Mod
     f = ibs_scalar_features(eeg1, eeg2, cfg)
     h = torch.relu(F.linear(f, sd["ibs_generator.proj.0.weight"], sd["ibs_generator.proj.0.bias"]))
     if p_drop > 0:
-        h = F.dropout(h, p_drop, True)
+        h = _dropout(h, p_drop, ("ibsgen",))
     return F.linear(h, sd["ibs_generator.proj.3.weight"], sd["ibs_generator.proj.3.bias"])
 
 
@@ -293,7 +308,7 @@ def mha(q_in: Tensor, kv_in: Tensor, sd: Dict[str, Tensor], pre: str, H: int, p_
     v = F.linear(kv_in, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"]).view(B, -1, H, dk).transpose(1, 2)
     s = (q @ k.transpose(-2, -1)) / math.sqrt(dk)
     p = torch.softmax(s, dim=-1)
-    pd = F.dropout(p, p_attn, True) if p_attn > 0 else p
+    pd = _dropout(p, p_attn, ("attn", pre))
     ctx = (pd @ v).transpose(1, 2).reshape(B, Tq, D)
     out = F.linear(ctx, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
     return (out, p) if return_probs else out
@@ -305,28 +320,30 @@ def _ln(x: Tensor, sd: Dict[str, Tensor], pre: str) -> Tensor:
 
 def encoder(x: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, p_drop: float = 0.0) -> Tensor:
     """6 x post-LN blocks + final LN (A:292-295, 326-328)."""
-    def drop(t):
-        return F.dropout(t, p_drop, True) if p_drop > 0 else t
     for l in range(cfg.num_layers):
         pre = f"encoder.layers.{l}."
         h = mha(x, x, sd, pre + "mha.", cfg.num_heads, p_drop)
-        x = _ln(x + drop(h), sd, pre + "ln1.")
+        x = _ln(x + _dropout(h, p_drop, ("drop1", l)), sd, pre + "ln1.")
         h = torch.relu(F.linear(x, sd[pre + "ffn.linear1.weight"], sd[pre + "ffn.linear1.bias"]))
-        h = drop(F.linear(drop(h), sd[pre + "ffn.linear2.weight"], sd[pre + "ffn.linear2.bias"]))
-        x = _ln(x + drop(h), sd, pre + "ln2.")
+        h = _dropout(F.linear(_dropout(h, p_drop, ("ffn_a", l)), sd[pre + "ffn.linear2.weight"], sd[pre + "ffn.linear2.bias"]),
+                     p_drop, ("ffn_b", l))
+        x = _ln(x + _dropout(h, p_drop, ("drop2", l)), sd, pre + "ln2.")
     return _ln(x, sd, "encoder.norm.")
 
 
 def cross_brain_attention(z1: Tensor, z2: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, p_drop: float = 0.0,
                           probs: Optional[list] = None):
     """Both directions share one MHA and one LN and read the pre-update z1, z2 (D:966-974)."""
-    def drop(t):
-        return F.dropout(t, p_drop, True) if p_drop > 0 else t
+    CTX["stream"] = 0
     c1, p1 = mha(z1, z2, sd, "cross_attn.cross_attn.", cfg.num_heads, p_drop, return_probs=True)
+    o1 = _ln(z1 + _dropout(c1, p_drop, ("xdrop1",)), sd, "cross_attn.norm.")
+    CTX["stream"] = 1
     c2, p2 = mha(z2, z1, sd, "cross_attn.cross_attn.", cfg.num_heads, p_drop, return_probs=True)
+    o2 = _ln(z2 + _dropout(c2, p_drop, ("xdrop1",)), sd, "cross_attn.norm.")
+    CTX["stream"] = 0
     if probs is not None:
         probs.extend([p1, p2])
-    return _ln(z1 + drop(c1), sd, "cross_attn.norm."), _ln(z2 + drop(c2), sd, "cross_attn.norm.")
+    return o1, o2
 
 
 # --------------------------------------------------------------------------------------
@@ -341,8 +358,11 @@ def forward(eeg1: Tensor, eeg2: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, la
     B = eeg1.shape[0]
     p = cfg.dropout if train else 0.0
     p01 = 0.1 if train else 0.0  # hard-coded sites D:161, D:84, D:866, D:216
+    CTX["stream"] = 0
     h1 = temporal_conv(eeg1, sd, cfg, p01)
+    CTX["stream"] = 1
     h2 = temporal_conv(eeg2, sd, cfg, p01)
+    CTX["stream"] = 0
     ibs_tokens = None
     if cfg.use_ibs:
         if cfg.use_robust_ibs:
@@ -371,8 +391,11 @@ def forward(eeg1: Tensor, eeg2: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, la
     seq1, seq2 = torch.cat(comps1, 1), torch.cat(comps2, 1)
     S = seq1.shape[1]
     pos = sd["pos_embed.pos_embed.weight"][:S]          # A:120-126 (learned)
+    CTX["stream"] = 0
     z1 = encoder(seq1 + pos, sd, cfg, p)
+    CTX["stream"] = 1
     z2 = encoder(seq2 + pos, sd, cfg, p)
+    CTX["stream"] = 0
     if stages is not None:
         stages.update(h1=h1, h2=h2, z1=z1, z2=z2)
         if ibs_tokens is not None:
@@ -393,8 +416,7 @@ def forward(eeg1: Tensor, eeg2: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, la
     f_pair = F.linear(comb, sd["symmetric_fusion.proj.weight"], sd["symmetric_fusion.proj.bias"])
     zf = torch.cat([f_pair, mp1, mp2], -1)                                            # D:1212
     hcl = torch.relu(F.linear(zf, sd["classifier.0.weight"], sd["classifier.0.bias"]))
-    if p > 0:
-        hcl = F.dropout(hcl, p, True)
+    hcl = _dropout(hcl, p, ("cls",))
     logits = F.linear(hcl, sd["classifier.3.weight"], sd["classifier.3.bias"])
     out = {"logits": logits, "cls1": cls1, "cls2": cls2}
     if cfg.use_ibs:
@@ -404,7 +426,7 @@ def forward(eeg1: Tensor, eeg2: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, la
             pooled = z1c[:, 1]                                                        # D:1228
         hi = torch.relu(F.linear(pooled, sd["ibs_classifier.0.weight"], sd["ibs_classifier.0.bias"]))
         if train:
-            hi = F.dropout(hi, 0.3, True)                                             # D:1077
+            hi = _dropout(hi, 0.3, ("ibscls",))                                       # D:1077
         out["ibs_logits"] = F.linear(hi, sd["ibs_classifier.3.weight"], sd["ibs_classifier.3.bias"])
         out["ibs_token"] = pooled
     if labels is not None:

@@ -376,3 +376,50 @@ def test_multimodal_fusion_step_reaches_the_hip_backward():
         np.testing.assert_allclose(q.grad.cpu().numpy(), p[n].grad.numpy(), atol=2e-6, err_msg=n)
     # and the encoder received it too
     assert float(dict(model.named_parameters())["encoder.layers.0.mha.q_proj.weight"].grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("name,dtype", [("cfg3_xattn", "f32"), ("cfg2_concat", "f32"), ("cfg3_xattn", "bf16")])
+def test_train_mode_matches_oracle_with_identical_masks(name, dtype):
+    """TRAIN mode, dropout on.  The oracle is fed exactly the masks the kernels draw (tests/helpers.py replicates the
+    counter hash on the CPU), so every dropout site, its scaling, its index convention and its backward are checked exactly
+    instead of statistically: loss, logits and all gradients as in the eval-mode gates."""
+    from tests.helpers import hip_dropout_override
+    z, kw, cfg, sd, model = build(name, dtype)
+    model.train()
+    kind, seed = "gen_eeg", 0x1234_5678_9ABC
+    x1c, x2c, labc = t(z[f"{kind}/eeg1"]), t(z[f"{kind}/eeg2"]), t(z["labels"])
+    B = x1c.shape[0]
+    eng = model.engine(B, x1c.shape[2], torch.device(DEV))
+    eng.set_state(seed=seed, lr=0.0, step=1)
+    eng.forward(x1c.to(DEV), x2c.to(DEV), labc.to(DEV), train=True)
+    eng.backward(gloss=torch.ones(1, device=DEV))
+    torch.cuda.synchronize()
+    got_logits, got_loss = eng.a["logits"].cpu().numpy(), float(eng.a["loss"])
+    # oracle with the same masks
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    O.DROPOUT_OVERRIDE = hip_dropout_override(seed, B, cfg.num_layers, O.CTX)
+    try:
+        out = O.forward(x1c, x2c, params, cfg, labc, train=True)
+        out["loss_ce"].backward()
+    finally:
+        O.DROPOUT_OVERRIDE = None
+    ref_logits = out["logits"].detach().numpy()
+    ltol, gtol = (2e-4, 2e-3) if dtype == "f32" else (5e-2, None)
+    assert np.abs(got_logits - ref_logits).max() <= ltol, np.abs(got_logits - ref_logits).max()
+    assert abs(got_loss - float(out["loss_ce"])) <= ltol
+    # masks really were active: train-mode logits differ from the eval fixture
+    assert np.abs(ref_logits - z[f"{kind}/out/logits"]).max() > 1e-3
+    fp = model._flat
+    gnorm_ref = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values() if p.grad is not None)))
+    gflat = fp.grad.cpu().double()
+    assert abs(float(gflat.norm()) / gnorm_ref - 1) < (5e-3 if dtype == "f32" else 8e-2)
+    if gtol:
+        for n, p in zip(fp.names, fp.params):
+            ref = params[n].grad
+            if ref is None:
+                continue
+            g = gflat[fp.offsets[n]: fp.offsets[n] + p.numel()].view(p.shape)
+            if float(ref.norm()) < 1e-5 * gnorm_ref:
+                assert float(g.norm()) < 1e-4 * gnorm_ref, n
+                continue
+            assert float((g - ref.double()).norm() / ref.double().norm()) < gtol, (n, float((g - ref.double()).norm() / ref.double().norm()))
