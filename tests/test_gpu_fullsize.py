@@ -1,0 +1,99 @@
+"""GPU tests at BASELINE.json's full size (B = 256 pairs of [8, 1024] windows per GPU, 33 280 token rows), where the CPU
+oracle is too slow to be the checker: size-independent properties the domain offers.
+  * batch independence: a sample's outputs do not depend on its batch (full batch == the same samples in batches of 4 / 32)
+  * determinism: two runs are bit-identical (no float atomics anywhere)
+  * gradient additivity: the mean-loss gradient of the full batch == the mean of its two halves' gradients (what DDP relies on)
+  * anchor: 4 of the 256 samples are a golden fixture's inputs; their logits still match the reference's."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from eyegaze_multimodal_amd.data import randn_windows  # noqa: E402
+from tests.helpers import t  # noqa: E402
+from tests.test_gpu_model import DEV, build  # noqa: E402
+
+B = 256
+
+
+def _inputs(z, kind="gen_eeg"):
+    x1, x2, y = randn_windows(B, 8, 1024, seed=77, num_classes=3)
+    x1[:4], x2[:4], y[:4] = t(z[f"{kind}/eeg1"]), t(z[f"{kind}/eeg2"]), t(z["labels"])
+    return x1.to(DEV), x2.to(DEV), y.to(DEV)
+
+
+@pytest.mark.parametrize("name", ["cfg2_concat", "cfg3_xattn"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_full_batch_outputs_are_batch_independent_and_anchored(name, dtype):
+    z, kw, cfg, sd, model = build(name, dtype)
+    model.eval()
+    x1, x2, y = _inputs(z)
+    with torch.no_grad():
+        full = model(x1, x2, y)
+        logits = full["logits"].clone()
+        again = model(x1, x2, y)["logits"]
+        assert torch.equal(logits, again)                                  # deterministic
+        small = torch.cat([model(x1[i:i + 4], x2[i:i + 4])["logits"] for i in (0, 100, 252)])
+        mid = model(x1[64:96], x2[64:96])["logits"]
+    ref = torch.cat([logits[0:4], logits[100:104], logits[252:256]])
+    tol = 1e-5 if dtype == "f32" else 0.0     # bf16: identical tiles -> identical bits; f32 attention sums per window too
+    assert float((small - ref).abs().max()) <= tol + 1e-6
+    assert float((mid - logits[64:96]).abs().max()) <= tol + 1e-6
+    err = np.abs(logits[:4].cpu().numpy() - z["gen_eeg/out/logits"]).max()
+    assert err <= (1e-4 if dtype == "f32" else 3e-2), err
+    assert (logits[:4].argmax(-1).cpu().numpy() == z["gen_eeg/out/argmax"]).all()
+    # the loss is the mean of the per-sample cross-entropies
+    ce = torch.nn.functional.cross_entropy(logits.float(), y)
+    assert abs(float(full["loss_ce"]) - float(ce)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_full_batch_gradient_is_the_mean_of_shard_gradients(dtype):
+    """Eval-mode gradients (no dropout): grad(B = 256) == (grad(first 128) + grad(last 128)) / 2 — the identity the
+    data-parallel all-reduce (mean over ranks) relies on — and repeated runs are bit-identical."""
+    z, kw, cfg, sd, model = build("cfg3_xattn", dtype)
+    model.eval()
+    x1, x2, y = _inputs(z)
+    one = torch.ones(1, device=DEV)
+
+    def grad(sl):
+        eng = model.engine(sl.stop - sl.start, 1024, torch.device(DEV))
+        eng.forward(x1[sl], x2[sl], y[sl], train=False)
+        eng.backward(gloss=one)
+        torch.cuda.synchronize()
+        return model._flat.grad.clone()
+    g_full = grad(slice(0, B))
+    assert torch.equal(g_full, grad(slice(0, B)))
+    g_mean = 0.5 * (grad(slice(0, B // 2)) + grad(slice(B // 2, B)))
+    assert torch.isfinite(g_full).all()
+    rel = float((g_full - g_mean).norm() / g_mean.norm())
+    # f32: summation order only.  bf16: the half-batch runs round the SAME per-sample activations identically; only the
+    # weight-gradient reductions (fp32) are split differently
+    assert rel < (2e-5 if dtype == "f32" else 2e-3), rel
+
+
+def test_full_size_train_step_moves_every_parameter_and_stays_finite():
+    z, kw, cfg, sd, model = build("cfg3_xattn", "bf16")
+    model.train()
+    from eyegaze_multimodal_amd import HipAdamW
+    x1, x2, y = _inputs(z)
+    eng = model.engine(B, 1024, torch.device(DEV))
+    opt = HipAdamW(model, lr=1e-4, weight_decay=0.01)
+    before = model._flat.flat.clone()
+    losses = []
+    for i in range(3):
+        opt.begin_step(eng, seed=10 + i)
+        eng.forward(x1, x2, y, train=True)
+        eng.backward(gloss=torch.ones(1, device=DEV))
+        opt.step(eng)
+        losses.append(float(eng.a["loss"]))
+    st = eng.read_state()
+    assert np.isfinite(losses).all() and np.isfinite(st.grad_norm) and st.grad_norm > 0
+    moved = (model._flat.flat != before)
+    # every parameter tensor moved (AdamW's first steps move each element by ~lr), except k_proj.bias (zero gradient,
+    # zero-initialised -> weight decay of 0 is 0)
+    fp = model._flat
+    for n, p in zip(fp.names, fp.params):
+        frac = float(moved[fp.offsets[n]: fp.offsets[n] + p.numel()].float().mean())
+        assert frac > 0.5 or n.endswith("k_proj.bias"), (n, frac)
