@@ -26,6 +26,10 @@ WORKLOADS = {
              "BASELINE configs[1]: two 1-D-conv streams + 6-layer Siamese encoder, concat fusion (no cross-attention)"),
     "cfg3": (dict(use_spectrogram=False, use_ibs=False, use_cross_attention=True),
              "BASELINE configs[2]/[3]: + bidirectional cross-stream attention fusion"),
+    "cfg5": (dict(use_spectrogram=True, use_ibs=False, use_cross_attention=True),
+             "BASELINE configs[4]: + STFT image -> 2-D CNN tokens per channel (third modality), cross-attention fusion"),
+    "a5": (dict(use_spectrogram=True, use_ibs=True, use_robust_ibs=True, use_cross_attention=True),
+           "reference default flags (A5): spectrogram tokens + 42 inter-stream synchrony tokens + cross-attention, loss_ce + loss_ibs_cls"),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
@@ -50,7 +54,7 @@ def cpu_baseline(kw, C, T, seconds_budget=25.0):
         for p in params.values():
             p.grad = None
         out = O.forward(x1, x2, params, cfg, labels, train=True)
-        out["loss_ce"].backward()
+        (out["loss_ce"] + (out["loss_ibs_cls"] if "loss_ibs_cls" in out else 0.0)).backward()   # lambda_ibs_cls = 1 (yaml :98)
         with torch.no_grad():
             O.clip_and_adamw({k: p.data for k, p in params.items()}, {k: p.grad for k, p in params.items()}, state, step=i + 1)
     step(0)
@@ -133,7 +137,8 @@ def main():
             return
         eng.probe_all = probes if probe else None
         eng.forward(x1, x2, labels, train=True)
-        eng.backward(gloss=one, on_segment=(reducer.on_segment if reducer else None))
+        eng.backward(gloss=one, gloss_ibs=(one if model.cfg.use_ibs else None),
+                     on_segment=(reducer.on_segment if reducer else None))
         eng.probe_all = None
         if reducer:
             reducer.finish()

@@ -476,11 +476,14 @@ def clip_and_adamw(params: Dict[str, Tensor], grads: Dict[str, Tensor], state: D
                    step: int, lr: float = 1e-4, wd: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8,
                    max_norm: float = 1.0) -> float:
     """In-place restatement of torch.nn.utils.clip_grad_norm_ followed by torch.optim.AdamW.step
-    (decoupled weight decay, bias-corrected moments).  Returns the pre-clip global L2 norm."""
-    total = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values()))
+    (decoupled weight decay, bias-corrected moments).  Returns the pre-clip global L2 norm.  Parameters whose gradient is
+    None are skipped, as torch does (e.g. ibs_classifier when its loss term is off)."""
+    total = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values() if g is not None))
     coef = min(1.0, max_norm / (total + 1e-6))
     b1, b2 = betas
     for k, p in params.items():
+        if grads[k] is None:
+            continue
         g = grads[k] * coef
         st = state.setdefault(k, {"m": torch.zeros_like(p), "v": torch.zeros_like(p)})
         p.mul_(1 - lr * wd)
