@@ -110,7 +110,7 @@ SIGNATURES = {
     "eg_ibs_analytic": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P, _P, _I, _P],
     "eg_ibs_pairs": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _I, _P],
     "eg_ibs_scalar": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _I, _I, _I, _I, _P],
-    "eg_affine_grad": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "eg_affine_grad": [_P, _P, _P, _I, _I, _I, _I, _P],
     "eg_ibs_inorm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eg_gelu_fwd": [_P, _P, _L, _I, _F, _U, _P, _P],
     "eg_gelu_bwd": [_P, _P, _P, _L, _I, _F, _U, _P, _P],

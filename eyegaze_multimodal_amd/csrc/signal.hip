@@ -387,15 +387,17 @@ __global__ void gelu_bwd_kernel(const T* __restrict__ u, const T* __restrict__ d
   Elem<T>::st(du + i, g * (cdf + v * pdf));
 }
 
-// InstanceNorm affine gradients: dgamma[e] = sum_m dy[m,e] * xhat[m,e], dbeta[e] = sum_m dy[m,e]
+// InstanceNorm affine gradients: dgamma[e] = sum_m dy[m,e] * xhat[m,e], dbeta[e] = sum_m dy[m,e].
+// grid (column blocks of 64, row splits): block (cb, sp) sums rows sp, sp + nsplit, ... of its 64 columns and writes
+// partial[sp][0][col] (gamma) / partial[sp][1][col] (beta); the caller sums the splits in order (eg_reduce_partials).
 template <typename T>
 __global__ __launch_bounds__(256) void affine_grad_kernel(const T* __restrict__ dy, const float* __restrict__ xhat,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int E) {
+                                                          float* __restrict__ partial, int M, int E, int nsplit) {
   __shared__ float rg[4][64], rb[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, sp = blockIdx.y;
   float g = 0.f, b = 0.f;
   if (col < E)
-    for (int m = rl; m < M; m += 4) {
+    for (int m = sp * 4 + rl; m < M; m += 4 * nsplit) {
       const float d = Elem<T>::ld(dy + (size_t)m * E + col);
       g = fmaf(d, xhat[(size_t)m * E + col], g);
       b += d;
@@ -405,8 +407,8 @@ __global__ __launch_bounds__(256) void affine_grad_kernel(const T* __restrict__ 
   __syncthreads();
   if (rl == 0 && col < E) {
     const int c = threadIdx.x & 63;
-    dgamma[col] = rg[0][c] + rg[1][c] + rg[2][c] + rg[3][c];
-    dbeta[col] = rb[0][c] + rb[1][c] + rb[2][c] + rb[3][c];
+    partial[((size_t)sp * 2 + 0) * E + col] = rg[0][c] + rg[1][c] + rg[2][c] + rg[3][c];
+    partial[((size_t)sp * 2 + 1) * E + col] = rb[0][c] + rb[1][c] + rb[2][c] + rb[3][c];
   }
 }
 
@@ -534,15 +536,15 @@ extern "C" int eg_gelu_bwd(const void* u, const void* dh, void* du, int64_t n, i
   return 0;
 }
 
-extern "C" int eg_affine_grad(const void* dy, const float* xhat, float* dgamma, float* dbeta, int M, int E, int dtype,
+extern "C" int eg_affine_grad(const void* dy, const float* xhat, float* partial, int nsplit, int M, int E, int dtype,
                               void* stream) {
-  EG_CHECK(dy && xhat && dgamma && dbeta && M > 0 && E > 0, "eg_affine_grad: bad arguments");
-  dim3 grid((E + 63) / 64);
+  EG_CHECK(dy && xhat && partial && M > 0 && E > 0 && nsplit > 0 && nsplit <= 65535, "eg_affine_grad: bad arguments");
+  dim3 grid((E + 63) / 64, nsplit);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == EG_BF16)
-    hipLaunchKernelGGL(affine_grad_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, xhat, dgamma, dbeta, M, E);
+    hipLaunchKernelGGL(affine_grad_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, xhat, partial, M, E, nsplit);
   else if (dtype == EG_F32)
-    hipLaunchKernelGGL(affine_grad_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, xhat, dgamma, dbeta, M, E);
+    hipLaunchKernelGGL(affine_grad_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, xhat, partial, M, E, nsplit);
   else
     return eg_fail("eg_affine_grad: bad dtype %d", dtype);
   EG_LAUNCH_CHECK("affine_grad");

@@ -105,6 +105,7 @@ def _alloc_bwd(model, eng: Engine):
             g["ib_dh"] = eng._t(B * ntok, 64)
             g["ib_du"] = eng._t(B * ntok, 64)
             g["ib_dxn"] = eng._t(B * ntok, E)
+            g["ib_affpart"] = eng._t(256, 2, E, dtype=torch.float32)
         else:
             g["ig_dtok"] = eng._t(B, d)
             g["ig_dh"] = eng._t(B, 2 * d)
@@ -253,8 +254,10 @@ def backward(model, eng: Engine, dseq):
         eng.wgrad(ptr(g["ib_du"]), ptr(a["ib_in"]), 0, M, 64, E, linear=[pre + "bottleneck.0"])
         if cfg.ibs_instance_norm:
             eng.gemm(ptr(g["ib_du"]), ptr(w["ib0T"]), ptr(g["ib_dxn"]), M, E, 64)
-            call("eg_affine_grad", ptr(g["ib_dxn"]), ptr(a["ib_xhat"]), fp.g_ptr(pre + "instance_norm.weight"),
-                 fp.g_ptr(pre + "instance_norm.bias"), M, E, dt, st)
+            nsp = min(256, (M + 3) // 4)
+            call("eg_affine_grad", ptr(g["ib_dxn"]), ptr(a["ib_xhat"]), ptr(g["ib_affpart"]), nsp, M, E, dt, st)
+            call("eg_reduce_partials", ptr(g["ib_affpart"]), fp.g_ptr(pre + "instance_norm.weight"), E, nsp, 2 * E, 0, st)
+            call("eg_reduce_partials", ptr(g["ib_affpart"]) + 4 * E, fp.g_ptr(pre + "instance_norm.bias"), E, nsp, 2 * E, 0, st)
     elif cfg.use_ibs:
         pre = "ibs_generator.proj."
         call("eg_rows_gather_gate", ptr(dseq), 0, ptr(g["ig_dtok"]), rowmap(d), B, S, d, 1, 1, B, 1.0, dt, st)

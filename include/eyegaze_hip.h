@@ -290,8 +290,9 @@ int eg_ibs_scalar(const float* xb, const float* phase, const float* spec, float*
                   void* stream);
 int eg_ibs_inorm(const float* conn, const int* fidx, const float* gamma, const float* beta, void* out, float* xhat, int B,
                  int nbands, int nfeat, int E, int use_norm, int dtype, void* stream);
-/* InstanceNorm affine gradients: dgamma[e] = sum_m dy[m,e]*xhat[m,e], dbeta[e] = sum_m dy[m,e] */
-int eg_affine_grad(const void* dy, const float* xhat, float* dgamma, float* dbeta, int M, int E, int dtype, void* stream);
+/* InstanceNorm affine gradients: dgamma[e] = sum_m dy[m,e]*xhat[m,e], dbeta[e] = sum_m dy[m,e], as nsplit row-split
+ * partials partial[sp][0][e] (gamma) | partial[sp][1][e] (beta); sum them in order with eg_reduce_partials */
+int eg_affine_grad(const void* dy, const float* xhat, float* partial, int nsplit, int M, int E, int dtype, void* stream);
 int eg_gelu_fwd(const void* u, void* h, int64_t n, int dtype, float drop_p, uint32_t drop_site, const eg_step_state* state,
                 void* stream);
 int eg_gelu_bwd(const void* u, const void* dh, void* du, int64_t n, int dtype, float drop_p, uint32_t drop_site,
