@@ -706,6 +706,17 @@ __global__ __launch_bounds__(256) void reduce_table_kernel(const eg_reduce_entry
   const eg_reduce_entry e = tab[ei_s];
   const float* partial = (const float*)e.partial;
   float* out = (float*)e.out;
+  if (e.splits <= EG_REDUCE_WIDE_SPLITS) {
+    // few splits (weight-gradient slabs): 256 float4 columns per block, each thread walks the splits in order --
+    // every load is a full-wave 1 KiB row and nothing goes through LDS
+    const long long i4 = ((long long)(blockIdx.x - e.blk0) * 256 + threadIdx.x) * 4;
+    if (i4 + 4 <= e.n) {
+      f32x4 t = *(const f32x4*)(partial + i4);
+      for (int k = 1; k < e.splits; ++k) t += *(const f32x4*)(partial + (size_t)k * e.stride + i4);
+      *(f32x4*)(out + i4) = t;
+    }
+    return;
+  }
   const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
   const long long i4 = ((long long)(blockIdx.x - e.blk0) * 8 + tx) * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};

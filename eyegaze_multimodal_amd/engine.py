@@ -35,6 +35,12 @@ def scramble_seed(seed: int) -> int:
     return z ^ (z >> 31)
 
 
+def _reduce_blocks(n: int, splits: int) -> int:
+    """workgroups eg_reduce_table spends on one entry (include/eyegaze_hip.h: EG_REDUCE_WIDE_SPLITS = 8)"""
+    cols = n // 4
+    return (cols + 255) // 256 if splits <= 8 else (cols + 7) // 8
+
+
 def _layer_sites(l: int):
     b = 16 + 8 * l
     return dict(attn=b, drop1=b + 1, ffn_a=b + 2, ffn_b=b + 3, drop2=b + 4)
@@ -461,7 +467,7 @@ class Engine:
             e.ldy, e.ldx, e.N, e.K, e.part_rows, e.has_bias, e.blk0 = ldy, K, N, K, N // len(names), 1, blk
             blk += ((N + 127) // 128) * ((K + 127) // 128) * splits
             r.partial, r.out, r.n, r.stride, r.splits, r.blk0 = base, fp.g_ptr(names[0] + ".weight"), slab, slab, splits, rblk
-            rblk += (slab // 4 + 7) // 8
+            rblk += _reduce_blocks(slab, splits)
             off += splits * slab
         for i, n in enumerate(ln_names):   # deferred LayerNorm gain / bias partials ride in the same reduce launch
             r = rt[len(probs) + i]
@@ -470,7 +476,7 @@ class Engine:
             # keeps the stand-alone kernel (its input gradient comes from encoder.norm, not from a product)
             fused = self.fuse_ln and not n.endswith(f"layers.{cfg.num_layers - 1}.ln2")
             r.n, r.stride, r.splits, r.blk0 = 2 * d, 2 * d, ((M + 63) // 64 if fused else self.LN_BLOCKS), rblk
-            rblk += (2 * d // 4 + 7) // 8
+            rblk += _reduce_blocks(2 * d, r.splits)
         dev = lambda arr: torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
         self._wg_plan = dict(tp=dev(tp), rt=dev(rt), n=len(probs), nr=len(probs) + len(ln_names), blocks=blk, rblocks=rblk,
                              splits=splits)

@@ -172,6 +172,9 @@ typedef struct eg_tn_problem {
   int64_t ldy, ldx;
   int32_t N, K, part_rows, has_bias, blk0, _pad;
 } eg_tn_problem;
+/* entry i owns blocks [blk0, blk0 + nblk): nblk = ceil(n/4 / 256) when splits <= EG_REDUCE_WIDE_SPLITS (one float4 column
+ * per thread, splits walked in order), else ceil(n/4 / 8) (8 float4 columns x 32 split lanes, for many short slabs) */
+#define EG_REDUCE_WIDE_SPLITS 8
 typedef struct eg_reduce_entry {
   uint64_t partial, out;
   int64_t n, stride;

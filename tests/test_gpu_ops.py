@@ -635,3 +635,26 @@ def test_gemm_row_tile_rejects_other_widths():
     d.M, d.N, d.K, d.ldw, d.dtype, d.row_tile = 64, 128, 64, 64, L.EG_BF16, 1
     with pytest.raises(L.EgError):
         call("eg_gemm_nt", C.byref(d), 0)
+
+
+def test_reduce_table_wide_and_narrow_entries():
+    """eg_reduce_table: entries with few splits take the one-column-per-thread path, entries with many short slabs the
+    8-column x 32-lane path; block ranges follow include/eyegaze_hip.h (EG_REDUCE_WIDE_SPLITS)."""
+    from eyegaze_multimodal_amd._lib import ReduceEntry
+    from eyegaze_multimodal_amd.engine import _reduce_blocks
+    g = torch.Generator().manual_seed(9)
+    specs = [(4096 + 36, 5), (512, 100), (1040, 8), (1040, 9), (4, 3), (262144 + 8, 2)]     # (n floats, splits); n % 4 == 0
+    parts = [torch.randn(s, n + 12, generator=g).to(DEV) for n, s in specs]                 # stride > n
+    outs = [torch.full((n + 4,), 7.0, device=DEV) for n, _ in specs]
+    tab = (ReduceEntry * len(specs))()
+    blk = 0
+    for e, (n, s), p, o in zip(tab, specs, parts, outs):
+        e.partial, e.out, e.n, e.stride, e.splits, e.blk0 = ptr(p), ptr(o), n, n + 12, s, blk
+        blk += _reduce_blocks(n, s)
+    dtab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(DEV)
+    call("eg_reduce_table", ptr(dtab), len(specs), blk, 0)
+    torch.cuda.synchronize()
+    for (n, s), p, o in zip(specs, parts, outs):
+        ref = p[:, :n].double().sum(0)
+        torch.testing.assert_close(o[:n].double().cpu(), ref.cpu(), rtol=1e-6, atol=1e-5)
+        assert float(o[n:].min()) == 7.0          # nothing written past n
