@@ -761,18 +761,27 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
-// conv weight gradient: partial [splits][N][Kp] in tap-major order (k = tap*Cp + c) -> dW [N][Cin][k] (parameter layout)
-__global__ void unpack_conv_wgrad_kernel(const float* __restrict__ partial, float* __restrict__ dW, int splits, int N,
-                                         int Cin, int k, int Cp, int Kp) {
-  // one thread per element of the tap-major slab (coalesced over the splits); the 4-B store is the scattered side
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)N * Kp) return;
-  const int n = (int)(i / Kp), kk = (int)(i % Kp);
-  const int tap = kk / Cp, c = kk % Cp;
-  if (tap >= k || c >= Cin) return;
-  float s = 0.f;
-  for (int sp = 0; sp < splits; ++sp) s += partial[(size_t)sp * N * Kp + i];
-  dW[((size_t)n * Cin + c) * k + tap] = s;
+// conv weight gradient: partial [splits][N][Kp] in tap-major order (k = tap*Cp + c) -> dW [N][Cin][k] (parameter layout).
+// One block per output channel n: the split sums are read as coalesced 16-B columns, the (tap, c) -> (c, tap) transposition
+// happens in LDS, and the [Cin*k] parameter row leaves as one contiguous stream.
+__global__ __launch_bounds__(256) void unpack_conv_wgrad_kernel(const float* __restrict__ partial, float* __restrict__ dW,
+                                                                int splits, int N, int Cin, int k, int Cp, int Kp) {
+  extern __shared__ __attribute__((aligned(16))) float row[];   // [Cin * k]
+  const int n = blockIdx.x;
+  const size_t slab = (size_t)N * Kp;
+  const float* src = partial + (size_t)n * Kp;
+  for (int i4 = threadIdx.x * 4; i4 < Kp; i4 += 4 * blockDim.x) {
+    f32x4 s = *(const f32x4*)(src + i4);
+    for (int sp = 1; sp < splits; ++sp) s += *(const f32x4*)(src + (size_t)sp * slab + i4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kk = i4 + e, tap = kk / Cp, c = kk - tap * Cp;
+      if (tap < k && c < Cin) row[c * k + tap] = s[e];
+    }
+  }
+  __syncthreads();
+  float* dst = dW + (size_t)n * Cin * k;
+  for (int j = threadIdx.x; j < Cin * k; j += blockDim.x) dst[j] = row[j];
 }
 
 // column sums of a [M, N] matrix: block b sums rows [b*rpb, (b+1)*rpb) -> partial[b, N]
@@ -967,8 +976,8 @@ extern "C" int eg_unpack_conv_wgrad(const float* partial, float* dW, int splits,
                                     void* stream) {
   EG_CHECK(partial && dW && splits > 0 && N > 0 && Cin > 0 && k > 0 && Cp >= Cin && Kp >= k * Cp,
            "eg_unpack_conv_wgrad: bad arguments");
-  const long long n = (long long)N * Kp;
-  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  EG_CHECK(Kp % 4 == 0 && (size_t)Cin * k * sizeof(float) <= 64 * 1024, "eg_unpack_conv_wgrad: Kp=%d must be a multiple of 4 and Cin*k*4 <= 64 KiB", Kp);
+  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(N), dim3(256), (size_t)Cin * k * sizeof(float), (hipStream_t)stream,
                      partial, dW, splits, N, Cin, k, Cp, Kp);
   EG_LAUNCH_CHECK("unpack_conv_wgrad");
   return 0;
