@@ -7,6 +7,9 @@ O=gpurun_out/final
 mkdir -p $O
 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 python bench.py --workload cfg3 --no-cpu-baseline > $O/bench_cfg3.json 2> $O/bench_cfg3.err
+python bench.py --workload cfg5 --no-cpu-baseline --steps 40 > $O/bench_cfg5.json 2> $O/bench_cfg5.err
+python bench.py --workload a5 --steps 40 > $O/bench_a5.json 2> $O/bench_a5.err
+python bench.py --graph --no-cpu-baseline > $O/bench_cfg2_graph.json 2> $O/bench_cfg2_graph.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o run -- python3 bench.py --no-cpu-baseline > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 > $O/pmc_write.log 2>&1
