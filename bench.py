@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
     ap.add_argument("--probe-dump", default=None, help="write the per-launch gemm_nt timings (shape, us, TFLOP/s, GB/s) to this file")
+    ap.add_argument("--h2d", default="none", choices=["none", "sync", "overlap"],
+                    help="PCIe-inclusive variant (never the headline value): copy the batch from pinned host memory every step, "
+                         "on the compute stream (sync) or double-buffered on a copy stream (overlap)")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: run the RCCL path with a single rank")
     args = ap.parse_args()
 
@@ -130,7 +133,41 @@ def main():
     # --graph replays captured hipGraphs instead (then the probe runs right after the timed region).
     graphed = GraphedStep(eng, opt, train=True, reducer=reducer) if (args.graph and world == 1) else None
 
+    host = None
+    if args.h2d != "none":
+        host = [t_.cpu().pin_memory() for t_ in (x1, x2, labels)]
+        dbuf = [[torch.empty_like(x1), torch.empty_like(x2), torch.empty_like(labels)] for _ in range(2)]
+        copy_stream = torch.cuda.Stream(dev)
+        copied = [torch.cuda.Event() for _ in range(2)]
+        used = [torch.cuda.Event() for _ in range(2)]
+
+        def stage(slot):            # host -> device of one batch on the copy stream
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(used[slot])
+                for d_, h_ in zip(dbuf[slot], host):
+                    d_.copy_(h_, non_blocking=True)
+                copied[slot].record(copy_stream)
+        for ev in used:
+            ev.record(torch.cuda.current_stream(dev))
+        if args.h2d == "overlap":
+            stage(0)
+
     def step(i, probe=False, eager=False):
+        nonlocal x1, x2, labels
+        if host is not None:
+            slot = i & 1
+            if args.h2d == "sync":
+                for d_, h_ in zip(dbuf[slot], host):
+                    d_.copy_(h_, non_blocking=True)
+            else:
+                torch.cuda.current_stream(dev).wait_event(copied[slot])
+                stage(slot ^ 1)     # the next batch travels while this one computes
+            x1, x2, labels = dbuf[slot]
+        _step(i, probe, eager)
+        if host is not None:
+            used[i & 1].record(torch.cuda.current_stream(dev))
+
+    def _step(i, probe=False, eager=False):
         opt.begin_step(eng, seed=1000 + i, grad_scale=(reducer.grad_scale if reducer else 1.0))
         if graphed is not None and not eager:
             graphed.run(x1, x2, labels)
@@ -216,7 +253,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "batch_per_gpu": B, "global_batch": world * B, "C": C, "T": T,
                        "seq_len": eng.S, "d_model": model.cfg.d_model, "layers": model.cfg.num_layers,
-                       "step": "fwd(train,dropout)+bwd+allreduce+clip+AdamW", "parallelism": f"dp{world}",
+                       "step": "fwd(train,dropout)+bwd+allreduce+clip+AdamW" + ("" if args.h2d == "none" else f" + per-step H2D ({args.h2d})"),
+                       "parallelism": f"dp{world}",
                        "final_loss": round(loss, 5)},
             "roofline": roof,
         }
