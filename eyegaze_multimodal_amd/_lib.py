@@ -105,6 +105,9 @@ SIGNATURES = {
     "eg_clip_coef": [_P, _I, _F, _P, _P],
     "eg_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P],
     "eg_fill_f32": [_P, _L, _F, _P],
+    "eg_aux_symmetry": [_P, _P, _P, _P, _P, _I, _I, _P],
+    "eg_aux_infonce": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P],
+    "eg_aux_supcon": [_P, _P, _F, _P, _P, _P, _I, _I, _P],
     "eg_fuzzy_gate_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P],
     "eg_fuzzy_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P],
     "eg_ibs_analytic": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P, _P, _I, _P],

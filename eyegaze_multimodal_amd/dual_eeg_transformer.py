@@ -185,6 +185,37 @@ class _HipFn(torch.autograd.Function):
         return (None, None, None, None, None, *grads)
 
 
+class _AuxLoss(torch.autograd.Function):
+    """loss, d loss / d tokens from one of the eg_aux_* kernels; backward = upstream scalar x the stored gradients."""
+
+    @staticmethod
+    def forward(ctx, kind, temperature, labels, *toks):
+        if not toks[0].is_cuda:
+            raise L.EgError("auxiliary losses (HIP) need device tensors; there is no CPU fallback")
+        toks = [t.detach().float().contiguous() for t in toks]
+        B, D = toks[0].shape
+        dev = toks[0].device
+        st = torch.cuda.current_stream(dev).cuda_stream
+        loss = torch.empty(1, device=dev)
+        grads = [torch.empty_like(t) for t in toks]
+        if kind == "sym":
+            L.call("eg_aux_symmetry", L.ptr(toks[0]), L.ptr(toks[1]), L.ptr(loss), L.ptr(grads[0]), L.ptr(grads[1]), B, D, st)
+        elif kind == "infonce":
+            work = torch.empty(3 * B * D + 4 * B + 2 * B * B, device=dev)
+            L.call("eg_aux_infonce", L.ptr(toks[0]), L.ptr(toks[1]), L.ptr(toks[2]), temperature, L.ptr(loss), L.ptr(grads[0]),
+                   L.ptr(grads[1]), L.ptr(grads[2]), L.ptr(work), B, D, st)
+        else:
+            lab = labels.to(device=dev, dtype=torch.int64).contiguous()
+            work = torch.empty(B * D + 5 * B + B * B + 4, device=dev)
+            L.call("eg_aux_supcon", L.ptr(toks[0]), L.ptr(lab), temperature, L.ptr(loss), L.ptr(grads[0]), L.ptr(work), B, D, st)
+        ctx.save_for_backward(*grads)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None, None, *[g * t for t in ctx.saved_tensors])
+
+
 class DualEEGTransformer(nn.Module):
     """Dual-stream window classifier, HIP engine behind the reference's module interface."""
 
@@ -291,30 +322,18 @@ class DualEEGTransformer(nn.Module):
         return out
 
     # ------------------------------------------------------------------------------------------
-    # auxiliary losses (D:1255-1371).  [B, d]-sized glue evaluated with torch ops on device: they are
-    # off by default in the reference config (dual_eeg_transformer.yaml:96-101) and sit outside the
-    # measured step; their gradients enter the HIP backward through cls1 / cls2 / ibs_token.
+    # auxiliary losses (D:1255-1371): HIP kernels (csrc/aux.hip) that return the loss together with its gradient w.r.t. the
+    # [B, d] tokens; autograd scales that gradient by the upstream scalar and hands it to the HIP backward through
+    # cls1 / cls2 / ibs_token.  Off by default in the reference config (dual_eeg_transformer.yaml:96-101).
     # ------------------------------------------------------------------------------------------
     def compute_symmetry_loss(self, cls1, cls2):
-        return ((cls1 - cls2) ** 2).mean()
+        return _AuxLoss.apply("sym", 0.0, None, cls1, cls2)
 
     def compute_ibs_alignment_loss(self, ibs_token, cls1, cls2, temperature: float = 0.07):
-        n = lambda t: t / t.norm(dim=-1, keepdim=True).clamp_min(1e-12)
-        sim = n(ibs_token) @ torch.cat([n(cls1), n(cls2)], 0).T / temperature
-        tgt = torch.arange(ibs_token.shape[0], device=ibs_token.device)
-        return (torch.logsumexp(sim, 1) - sim.gather(1, tgt[:, None]).squeeze(1)).mean()
+        return _AuxLoss.apply("infonce", float(temperature), None, ibs_token, cls1, cls2)
 
     def compute_ibs_contrastive_loss(self, ibs_tokens, labels, temperature: float = 0.07):
-        Bn = ibs_tokens.shape[0]
-        z = ibs_tokens / ibs_tokens.norm(dim=1, keepdim=True).clamp_min(1e-12)
-        e = torch.exp(z @ z.T / temperature)
-        eye = torch.eye(Bn, dtype=torch.bool, device=z.device)
-        pos = (labels[:, None] == labels[None, :]).float().masked_fill(eye, 0)
-        has = pos.sum(1) > 0
-        if int(has.sum()) == 0:
-            return torch.tensor(0.0, device=z.device)
-        loss = -torch.log((e * pos).sum(1) / (e.masked_fill(eye, 0).sum(1) + 1e-8) + 1e-8)
-        return loss[has].mean()
+        return _AuxLoss.apply("supcon", float(temperature), labels, ibs_tokens)
 
     # ------------------------------------------------------------------------------------------
     # hooks the engine calls for the optional token families (spectrogram / synchrony tokens)

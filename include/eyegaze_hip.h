@@ -247,6 +247,20 @@ int eg_batch_rowsum(const void* dseq, float* out, int NB, int S, int D, int rows
 int eg_rows_gather_gate(const void* src, const void* gate, void* dst, eg_rowmap dmap, int nb, int S, int D, int R,
                         int off, int pair_shift, float gate_scale, int dtype, void* stream);
 
+/* Batch-level auxiliary losses (3_Models/backbones/dual_eeg_transformer.py:1255-1371), fp32, each with the gradient of the
+ * loss w.r.t. the [B, D] tokens it reads (upstream gradient 1; the caller scales).  B <= 1024.
+ *   eg_aux_symmetry  F.mse_loss(cls1, cls2)                                                                    :1255-1260
+ *   eg_aux_infonce   cross_entropy(normalize(ibs) normalize(cat[cls1, cls2])^T / temperature, arange(B))       :1262-1304
+ *                    work: 3*B*D + 4*B + 2*B*B floats
+ *   eg_aux_supcon    supervised contrastive loss over normalize(ibs) with the reference's 1e-8 guards, mean over the rows
+ *                    that have a same-label partner, 0 (and zero gradient) if none has                          :1306-1371
+ *                    work: B*D + 5*B + B*B + 4 floats */
+int eg_aux_symmetry(const float* cls1, const float* cls2, float* loss, float* d_cls1, float* d_cls2, int B, int D, void* stream);
+int eg_aux_infonce(const float* ibs, const float* cls1, const float* cls2, float temperature, float* loss, float* d_ibs,
+                   float* d_cls1, float* d_cls2, float* work, int B, int D, void* stream);
+int eg_aux_supcon(const float* ibs, const int64_t* labels, float temperature, float* loss, float* d_ibs, float* work, int B,
+                  int D, void* stream);
+
 /* FuzzyGatingFusion.forward — 3_Models/fusion/fuzzy_gating_fusion.py:297-390 (config 5's logit-level fusion).
  * params = [tau_img, tau_eeg, c_unreliable_img, c_unreliable_eeg, log_sigma_reliable_img, log_sigma_reliable_eeg,
  *           log_sigma_unreliable_img, log_sigma_unreliable_eeg, beta[4]] (12 device floats);

@@ -423,3 +423,47 @@ def test_train_mode_matches_oracle_with_identical_masks(name, dtype):
                 assert float(g.norm()) < 1e-4 * gnorm_ref, n
                 continue
             assert float((g - ref.double()).norm() / ref.double().norm()) < gtol, (n, float((g - ref.double()).norm() / ref.double().norm()))
+
+
+def test_auxiliary_losses_and_their_gradients():
+    """csrc/aux.hip against (i) the values the reference produced on the fixture's fixed (ibs, cls1, cls2, labels) and (ii) the
+    oracle's autograd gradients; larger random batches against the oracle; the no-positive-pair case returns 0 with zero
+    gradient."""
+    z, kw, cfg, sd, model = build("cfg3_xattn", "f32")
+    ibs, c1, c2 = (t(z[f"aux/{k}"]) for k in ("ibs", "cls1", "cls2"))
+    lab = t(z["aux/labels"])
+    d = lambda v: v.to(DEV).requires_grad_(True)
+    assert abs(float(model.compute_symmetry_loss(d(c1), d(c2))) - float(z["aux/sym"])) < 1e-6
+    assert abs(float(model.compute_ibs_alignment_loss(d(ibs), d(c1), d(c2))) - float(z["aux/align"])) < 1e-5
+    assert abs(float(model.compute_ibs_contrastive_loss(d(ibs), lab.to(DEV))) - float(z["aux/contrastive"])) < 1e-5
+    g = torch.Generator().manual_seed(2)
+    for B, D in ((ibs.shape[0], ibs.shape[1]), (64, 256), (256, 256), (300, 96)):
+        if B == ibs.shape[0]:
+            a, b1, b2, y = ibs, c1, c2, lab
+        else:
+            a, b1, b2 = (torch.randn(B, D, generator=g) for _ in range(3))
+            b1 = b1 + 0.5 * a                     # some alignment, so the soft-max is not flat
+            y = torch.randint(0, 3, (B,), generator=g)
+        for kind in ("sym", "infonce", "supcon"):
+            ra, r1, r2 = (v.clone().requires_grad_(True) for v in (a, b1, b2))
+            ga, g1, g2 = d(a), d(b1), d(b2)
+            if kind == "sym":
+                ref, got = O.symmetry_loss(r1, r2), model.compute_symmetry_loss(g1, g2)
+            elif kind == "infonce":
+                ref, got = O.ibs_alignment_loss(ra, r1, r2), model.compute_ibs_alignment_loss(ga, g1, g2)
+            else:
+                ref, got = O.ibs_contrastive_loss(ra, y), model.compute_ibs_contrastive_loss(ga, y.to(DEV))
+            (3.0 * ref).backward()
+            (3.0 * got).backward()                # a non-unit upstream gradient
+            assert abs(float(got) - float(ref)) < 2e-5 * max(1.0, abs(float(ref))), (kind, B, float(got), float(ref))
+            for name, rv, gv in (("ibs", ra, ga), ("cls1", r1, g1), ("cls2", r2, g2)):
+                if rv.grad is None:
+                    assert gv.grad is None or float(gv.grad.abs().max()) == 0.0
+                    continue
+                err = float((gv.grad.cpu() - rv.grad).abs().max())
+                assert err < 2e-5 * max(1e-3, float(rv.grad.abs().max())) + 1e-8, (kind, name, B, err)
+    # no row has a same-label partner -> loss 0, gradient 0 (D:1346-1349)
+    x = d(ibs[:3])
+    l0 = model.compute_ibs_contrastive_loss(x, torch.tensor([0, 1, 2], device=DEV))
+    l0.backward()
+    assert float(l0) == 0.0 and float(x.grad.abs().max()) == 0.0
