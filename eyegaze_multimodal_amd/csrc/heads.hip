@@ -47,7 +47,8 @@ __global__ void pool_fuse_fwd_kernel(const T* __restrict__ z, float* __restrict_
     Elem<T>::st(comb + (size_t)b * 3 * D + D + n, a * c);
     Elem<T>::st(comb + (size_t)b * 3 * D + 2 * D + n, fabsf(a - c));
     float m1 = 0.f, m2 = 0.f;
-    for (int s = off; s < S; ++s) {
+#pragma unroll 8
+    for (int s = off; s < S; ++s) {          // unrolled: 16 independent 2-byte loads in flight instead of 2
       m1 += Elem<T>::ld(z1 + (size_t)s * D + n);
       m2 += Elem<T>::ld(z2 + (size_t)s * D + n);
     }
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(256) void classifier_wgrad_kernel(const T* __restri
   __shared__ float red[4][64], redb[4];
   const int c = blockIdx.x, k = blockIdx.y * 64 + (threadIdx.x & 63), bl = threadIdx.x >> 6;
   float s = 0.f, sb = 0.f;
+#pragma unroll 8
   for (int b = bl; b < B; b += 4) {
     const float dl = dlogits[(size_t)b * ncls + c];
     if (k < K) s = fmaf(dl, Elem<T>::ld(h + (size_t)b * K + k), s);
