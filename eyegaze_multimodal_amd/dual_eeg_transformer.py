@@ -176,6 +176,8 @@ class _HipFn(torch.autograd.Function):
         one = lambda t: None if t is None else t.reshape(1)
         eng.backward(gloss=one(g.get("loss_ce")), gloss_ibs=one(g.get("loss_ibs_cls")), glogits=g.get("logits"),
                      gcls1=g.get("cls1"), gcls2=g.get("cls2"), gibs_logits=g.get("ibs_logits"), gibs_token=g.get("ibs_token"))
+        from . import tokens
+        tokens.fire_spec_backward_hooks(model, eng)
         fp = model._flat
         flat = fp.grad.clone()
         grads = []
@@ -309,7 +311,10 @@ class DualEEGTransformer(nn.Module):
             labels = labels.to(device=eeg1.device, dtype=torch.int64).contiguous()
         eeg1, eeg2 = eeg1.contiguous().float(), eeg2.contiguous().float()
         eng = self.engine(eeg1.shape[0], eeg1.shape[2], eeg1.device)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self._flat.params):
+        # autograd node when anything upstream or inside wants gradients; analysis code (Grad-CAM) freezes the parameters and
+        # marks the INPUTS instead: the HIP path has no gradient w.r.t. the raw windows (the reference never trains through
+        # them either), their .grad stays None, but the backward still runs and feeds the hooks
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self._flat.params) or eeg1.requires_grad or eeg2.requires_grad):
             vals = _HipFn.apply(self, eng, eeg1, eeg2, labels, *self._flat.params)
             keys = ["logits", "cls1", "cls2"] + (["ibs_logits", "ibs_token"] if self.cfg.use_ibs else [])
             if labels is not None:

@@ -224,6 +224,17 @@ def forward(model, eng: Engine, eeg1, eeg2, train: bool):
         row = (Wp + 4) * 32
         eng.gemm(ptr(a["sp_p1"]), ptr(w["spc2"]), ptr(a["sp_out2"]), sp["rows"], 64, 384, a=rowmap(32, row, Wp), seg=(128, row),
                  bias=fp.p_ptr(pre + "spec_conv.3.bias"), act=L.ACT_RELU)
+        conv2 = model.spectrogram_generator.spec_conv[3]
+        if conv2._forward_hooks:
+            # Grad-CAM contract (5_Metrics/eeg_metrics.py:742-764): a forward hook on spec_conv[3] sees that layer's output
+            # (before the ReLU the production GEMM fuses), once per stream, as [B*C, 64, H', W']
+            tmp = torch.empty_like(a["sp_out2"])
+            eng.gemm(ptr(a["sp_p1"]), ptr(w["spc2"]), ptr(tmp), sp["rows"], 64, 384, a=rowmap(32, row, Wp), seg=(128, row),
+                     bias=fp.p_ptr(pre + "spec_conv.3.bias"))
+            act = tmp.view(nimg, Hp + 2, Wp, 64)[:, :Hp].permute(0, 3, 1, 2).float()
+            for half in (act[: nimg // 2], act[nimg // 2:]):
+                for hook in list(conv2._forward_hooks.values()):
+                    hook(conv2, (None,), half.contiguous())
         call("eg_spec_avgpool_fwd", ptr(a["sp_out2"]), ptr(a["sp_pooled"]), nimg, Hp, Wp, dt, st)
         eng.gemm(ptr(a["sp_pooled"]), ptr(w["spp0"]), ptr(a["sp_hp0"]), nimg, 2 * d, 1024, bias=fp.p_ptr(pre + "proj.0.bias"),
                  act=L.ACT_RELU, drop1=(p01, SITE_SPEC))
@@ -284,3 +295,21 @@ def backward(model, eng: Engine, dseq):
              ptr(g["sp_dp1"]), ptr(g["sp_part"]), nimg, F, nfr, dt, st)
         call("eg_reduce_partials", ptr(g["sp_part"]), fp.g_ptr(pre + "spec_conv.0.weight"), 288, nimg, 320, 0, st)
         call("eg_reduce_partials", ptr(g["sp_part"]) + 288 * 4, fp.g_ptr(pre + "spec_conv.0.bias"), 32, nimg, 320, 0, st)
+
+
+def fire_spec_backward_hooks(model, eng: Engine):
+    """Full backward hooks on spectrogram_generator.spec_conv[3] (Grad-CAM, eeg_metrics.py:758-764) receive
+    grad_output = d score / d (that layer's output), stream 2 first (autograd runs the second call's backward first)."""
+    if not eng.cfg.use_spectrogram:
+        return
+    conv2 = model.spectrogram_generator.spec_conv[3]
+    hooks = list(getattr(conv2, "_backward_hooks", {}).values())
+    if not hooks:
+        return
+    sp = eng.sp
+    Hp, Wp, nimg = sp["Hp"], sp["Wp"], sp["nimg"]
+    d2 = eng.g["sp_d2"][: nimg * (Hp + 2) * (Wp + 4) * 64].view(nimg, Hp + 2, Wp + 4, 64)
+    grad = d2[:, 1: Hp + 1, 1: Wp + 1].permute(0, 3, 1, 2).float()
+    for half in (grad[nimg // 2:], grad[: nimg // 2]):
+        for hook in hooks:
+            hook(conv2, (None,), (half.contiguous(),))

@@ -101,6 +101,7 @@ SCALAR_BANDS: List[Tuple[float, float]] = [(4, 8), (8, 13), (13, 30), (30, 45)]
 # ("ibstok",) ("ibsgen",), and CTX["stream"] says which of the two streams (or cross-attention directions) is being computed.
 DROPOUT_OVERRIDE = None
 CTX = {"stream": 0}
+SPEC_CONV2_TAPS = None   # tests may set this to a list: spectrogram_tokens appends its second conv's output (pre-ReLU)
 
 
 def _dropout(t: Tensor, p: float, site) -> Tensor:
@@ -154,6 +155,10 @@ def spectrogram_tokens(x: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, p_drop: 
     h = F.conv2d(img, sd[pre + "spec_conv.0.weight"], sd[pre + "spec_conv.0.bias"], padding=1)
     h = F.max_pool2d(torch.relu(h), 2)
     h = F.conv2d(h, sd[pre + "spec_conv.3.weight"], sd[pre + "spec_conv.3.bias"], padding=1)
+    if SPEC_CONV2_TAPS is not None:          # what a hook on spec_conv[3] sees (Grad-CAM, eeg_metrics.py:742-764)
+        if h.requires_grad:
+            h.retain_grad()
+        SPEC_CONV2_TAPS.append(h)
     h = F.adaptive_avg_pool2d(torch.relu(h), (4, 4)).flatten(1)
     h = torch.relu(F.linear(h, sd[pre + "proj.0.weight"], sd[pre + "proj.0.bias"]))
     if p_drop > 0:

@@ -87,3 +87,49 @@ def test_ibs_matrix_generator_hooks():
     # hooks removed -> baseline again
     with torch.no_grad():
         np.testing.assert_allclose(model(x1, x2)["logits"].cpu().numpy(), base, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype,rtol", [("f32", 2e-3), ("bf16", 6e-2)])
+def test_gradcam_hooks_on_spec_conv(dtype, rtol):
+    """The reference's GradCAM class (eeg_metrics.py:742-830) on the HIP module: forward hook + full backward hook on
+    spectrogram_generator.spec_conv[3], parameters frozen, inputs marked requires_grad, score = sum of predicted logits.
+    Expected tensors: tests/golden/gradcam.npz (oracle/make_golden_gradcam.py, from the reference)."""
+    gz = np.load(GOLDEN / "gradcam.npz", allow_pickle=False)
+    z, kw, cfg, sd, model = build("cfg5_a2_spec", dtype)
+    model.eval()
+    for p in model.parameters():
+        p.requires_grad = False
+    x1 = t(z["gen_eeg/eeg1"]).to(DEV).requires_grad_(True)
+    x2 = t(z["gen_eeg/eeg2"]).to(DEV).requires_grad_(True)
+    acts, grads = [], []
+    layer = model.spectrogram_generator.spec_conv[3]
+    h1 = layer.register_forward_hook(lambda m, i, o: acts.append(o.detach()))
+    h2 = layer.register_full_backward_hook(lambda m, gi, go: grads.append(go[0].detach()))
+    model.zero_grad()
+    out = model(x1, x2)
+    logits = out["logits"]
+    pred = logits.argmax(-1)
+    assert (pred.cpu().numpy() == gz["pred"]).all()
+    logits[torch.arange(logits.shape[0], device=DEV), pred].sum().backward()
+    h1.remove(), h2.remove()
+    assert len(acts) == 2 and len(grads) == 2 and tuple(acts[0].shape) == tuple(gz["shape"])
+    C = cfg.in_channels
+    for s_ in range(2):
+        a, ra = acts[s_][:C].cpu().numpy(), gz["act"][s_]
+        assert np.abs(a - ra).max() <= rtol * np.abs(ra).max(), (s_, np.abs(a - ra).max())
+        g, rg = grads[s_][:C].cpu().numpy(), gz["grad_in_hook_order"][s_]           # stream 2 first, as under autograd
+        if dtype == "f32":
+            assert np.abs(g - rg).max() <= rtol * np.abs(rg).max() + 1e-9, (s_, np.abs(g - rg).max(), np.abs(rg).max())
+        else:   # bf16 gradients through six encoder layers: held to direction and scale (DESIGN.md section 4), as the parameter gradients are
+            cos = float((g * rg).sum() / (np.linalg.norm(g) * np.linalg.norm(rg)))
+            assert cos > 0.8 and 0.7 < np.linalg.norm(g) / np.linalg.norm(rg) < 1.4, (s_, cos)
+    # the CAM the reference's generate_cam computes from them (gradients reversed into forward order)
+    w = torch.stack(grads).mean(dim=(3, 4), keepdim=True)
+    cam = torch.relu((w * torch.stack(acts[::-1])).sum(2))[:, :C].cpu().numpy()
+    ref = gz["cam_stream2_then_1"]
+    if dtype == "f32":
+        assert np.abs(cam - ref).max() <= 2 * rtol * np.abs(ref).max() + 1e-9
+    else:
+        assert float(np.corrcoef(cam.ravel(), ref.ravel())[0, 1]) > 0.8
+    # without hooks the carriers are skipped and frozen parameters get no gradient
+    assert all(p.grad is None for p in model.parameters()) and x1.grad is None
