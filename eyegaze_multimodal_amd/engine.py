@@ -478,14 +478,39 @@ class Engine:
             r.n, r.stride, r.splits, r.blk0 = 2 * d, 2 * d, ((M + 63) // 64 if fused else self.LN_BLOCKS), rblk
             rblk += _reduce_blocks(2 * d, r.splits)
         dev = lambda arr: torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        # the same problems as per-layer tables (block ranges relative to the layer's own launch): used when the weight
+        # gradients of a layer are launched on the side stream as soon as that layer's backward-data chain has produced them
+        per_layer = []
+        for l in range(cfg.num_layers):
+            sub = (L.TNProblem * 4)()
+            b0 = tp[4 * l].blk0
+            for j in range(4):
+                C.memmove(C.addressof(sub[j]), C.addressof(tp[4 * l + j]), C.sizeof(L.TNProblem))
+                sub[j].blk0 = tp[4 * l + j].blk0 - b0
+            nblk = (tp[4 * l + 4].blk0 if l + 1 < cfg.num_layers else blk) - b0
+            per_layer.append((dev(sub), nblk))
         self._wg_plan = dict(tp=dev(tp), rt=dev(rt), n=len(probs), nr=len(probs) + len(ln_names), blocks=blk, rblocks=rblk,
-                             splits=splits)
+                             splits=splits, per_layer=per_layer)
         return self._wg_plan
 
     def _wgrad_group_launch(self):
         pl = self._wg_plan
-        call("eg_gemm_tn_grouped", ptr(pl["tp"]), pl["n"], pl["blocks"], self.M, pl["splits"], self.dtype, self.stream)
+        if self._wg_side is not None:          # the per-layer launches are already queued on the side stream: join it
+            torch.cuda.current_stream(self.device).wait_stream(self._wg_side)
+        else:
+            call("eg_gemm_tn_grouped", ptr(pl["tp"]), pl["n"], pl["blocks"], self.M, pl["splits"], self.dtype, self.stream)
         call("eg_reduce_table", ptr(pl["rt"]), pl["nr"], pl["rblocks"], self.stream)
+
+    def _wgrad_layer_async(self, l: int):
+        """Weight gradients of encoder layer l on the side stream, behind an event recorded after the layer's backward-data
+        chain: they are independent of everything the main stream does until the final reduce, and the latency-bound K = 256
+        products of the lower layers leave room for them (EYEGAZE_WGRAD_OVERLAP=1)."""
+        tab, nblk = self._wg_plan["per_layer"][l]
+        cur = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._wg_side.wait_event(ev)
+        call("eg_gemm_tn_grouped", ptr(tab), 4, nblk, self.M, self._wg_plan["splits"], self.dtype, self._wg_side.cuda_stream)
 
     def _ln_f(self, gname, y, stats):
         """forward LayerNorm spec for gemm(ln=...) — None when the fused epilogue is unavailable (d_model != 256)"""
@@ -732,6 +757,11 @@ class Engine:
         other = g["dzB"]
 
         grouped = self._wgrad_group_plan() is not None
+        overlap = (grouped and os.environ.get("EYEGAZE_WGRAD_OVERLAP", "0") == "1" and self.device.type == "cuda"
+                   and not torch.cuda.is_current_stream_capturing())
+        if overlap and getattr(self, "_wg_side_stream", None) is None:
+            self._wg_side_stream = torch.cuda.Stream(self.device)
+        self._wg_side = self._wg_side_stream if overlap else None
 
         def attn_block_bwd(pre, l, x_in, dr, drm, kv_shift, site_attn, dx_out, dqkv, defer, ln_next=None):
             """dr: grad of the pre-LN sum (residual path), drm: same, masked by the branch dropout.
@@ -805,6 +835,8 @@ class Engine:
                                       d2=(p, sl["drop2"]), slot=sn)
                            if has_drop else self._ln_b(pl + "ln2", a[f"r2_{l - 1}"], a[f"st2_{l - 1}"], dYf_n, None, slot=sn))
             attn_block_bwd(pre + "mha.", l, a[f"x{l}"], dr, dYo, 0, sites["attn"], other, dqkv, grouped, ln_next)
+            if overlap:
+                self._wgrad_layer_async(l)
             dz, other = other, dz
             if not grouped:
                 seg(f"layer{l}")

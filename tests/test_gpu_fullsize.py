@@ -97,3 +97,23 @@ def test_full_size_train_step_moves_every_parameter_and_stays_finite():
     for n, p in zip(fp.names, fp.params):
         frac = float(moved[fp.offsets[n]: fp.offsets[n] + p.numel()].float().mean())
         assert frac > 0.5 or n.endswith("k_proj.bias"), (n, frac)
+
+
+def test_overlapped_weight_gradient_launches_are_bit_identical(monkeypatch):
+    """EYEGAZE_WGRAD_OVERLAP=1 queues each layer's weight-gradient products on a side stream behind an event; the same
+    kernels write the same partial slabs, so the reduced gradients must equal the single grouped launch bit for bit."""
+    z, kw, cfg, sd, model = build("cfg3_xattn", "bf16")
+    model.train()
+    x1, x2, y = _inputs(z)
+    one = torch.ones(1, device=DEV)
+    grads = []
+    for flag in ("0", "1", "1"):
+        monkeypatch.setenv("EYEGAZE_WGRAD_OVERLAP", flag)
+        eng = model.engine(B, 1024, torch.device(DEV))
+        eng.set_state(seed=99, lr=0.0, step=1)
+        eng.forward(x1, x2, y, train=True)
+        eng.backward(gloss=one)
+        torch.cuda.synchronize()
+        assert (eng._wg_side is not None) == (flag == "1")
+        grads.append(model._flat.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[1], grads[2])
