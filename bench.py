@@ -3,8 +3,13 @@
 
 A step = forward (train mode, dropout on) + backward + gradient all-reduce (N > 1) + clip_grad_norm_(1.0) + AdamW
 over one batch of synthetic [B=256, C=8, T=1024] window pairs per GPU, inputs resident in HBM.
-Workload = BASELINE.json configs[1] (two 1-D-conv streams, concat fusion, bf16, batch 256) unless --workload says
-otherwise.  Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+Workload = BASELINE.json configs[2]/[3] (two 1-D-conv streams + bidirectional cross-stream attention fusion, bf16, batch 256
+per GPU: the configuration the 1/2/4/8-GPU metric is quoted on) unless --workload says otherwise.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+
+Ranks: under torchrun (WORLD_SIZE set) this process IS one rank.  Started plainly with --gpus N > 1 it becomes a launcher:
+it spawns N fresh rank processes (before touching the GPU itself -- a process that has initialised HIP is never re-executed),
+relays rank 0's JSON line and exits with the worst child status.
 """
 import argparse
 import json
@@ -36,9 +41,40 @@ PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0     # HBM3E, MI355X_MICROARCH.md (about 6.3 TB/s is reachable by a streaming kernel)
 
 
-def cpu_baseline(kw, C, T, seconds_budget=25.0):
+def plan_ranks(gpus: int, env: dict, share_gpu: bool = False, port: int = 0):
+    """Environment of every child rank the launcher starts (one process per GPU, rendezvous on 127.0.0.1).
+    Returns [] when this process must run as a rank itself (N == 1, or a launcher such as torchrun already set WORLD_SIZE)."""
+    if gpus <= 1 or "WORLD_SIZE" in env:
+        return []
+    if not port:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    out = []
+    for r in range(gpus):
+        e = dict(env)
+        e.update(WORLD_SIZE=str(gpus), RANK=str(r), LOCAL_RANK=str(0 if share_gpu else r), LOCAL_WORLD_SIZE=str(gpus),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out.append(e)
+    return out
+
+
+def launch_ranks(plans) -> int:
+    """Starts one fresh interpreter per rank with this script's own arguments; rank 0's stdout is relayed verbatim."""
+    import subprocess
+    procs = [subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=e,
+                              stdout=(None if i == 0 else subprocess.DEVNULL)) for i, e in enumerate(plans)]
+    rc = 0
+    for p_ in procs:
+        rc = max(rc, abs(p_.wait()))
+    return rc
+
+
+def cpu_baseline(kw, C, T, Bc=256, seconds_budget=30.0):
     """The CPU oracle (oracle/dual_eeg_oracle.py, kind 'port') timed on this host: train-mode forward + backward +
-    clip + AdamW on a bounded sample (B=32) of the same synthetic workload."""
+    clip + AdamW on the same synthetic workload at the same batch (B = 256, fp32, all granted cores,
+    1 warm-up step, then up to 3 timed steps inside a bounded time budget)."""
     from oracle import dual_eeg_oracle as O
     from eyegaze_multimodal_amd.data import randn_windows
     cores = min(16, len(os.sched_getaffinity(0)))  # the GPU box grants a 16-core share per GPU
@@ -46,7 +82,6 @@ def cpu_baseline(kw, C, T, seconds_budget=25.0):
     cfg = O.ModelCfg(in_channels=C, max_len=T // 4, **kw)
     sd = O.synthetic_state_dict(cfg, seed=1)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    Bc = 32
     x1, x2, labels = randn_windows(Bc, C, T, seed=1234, num_classes=cfg.num_classes)
     state = {}
 
@@ -57,10 +92,12 @@ def cpu_baseline(kw, C, T, seconds_budget=25.0):
         (out["loss_ce"] + (out["loss_ibs_cls"] if "loss_ibs_cls" in out else 0.0)).backward()   # lambda_ibs_cls = 1 (yaml :98)
         with torch.no_grad():
             O.clip_and_adamw({k: p.data for k, p in params.items()}, {k: p.grad for k, p in params.items()}, state, step=i + 1)
+    tw = time.perf_counter()
     step(0)
+    tw = time.perf_counter() - tw
     t0 = time.perf_counter()
     n = 0
-    while n < 2 or (time.perf_counter() - t0 < seconds_budget / 2 and n < 8):
+    while n < 1 or (n < 3 and (time.perf_counter() - t0) + tw * 1.1 < seconds_budget):
         step(n + 1)
         n += 1
     dt = (time.perf_counter() - t0) / n
@@ -73,7 +110,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=256, help="windows pairs per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -86,14 +123,36 @@ def main():
                     help="PCIe-inclusive variant (never the headline value): copy the batch from pinned host memory every step, "
                          "on the compute stream (sync) or double-buffered on a copy stream (overlap)")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: run the RCCL path with a single rank")
+    ap.add_argument("--cpu-batch", type=int, default=256, help="batch of the CPU baseline leg (SURVEY 8d: 256)")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="rehearsal without a GPU: form the process group, report world/rank and exit (CPU test of the launcher)")
     args = ap.parse_args()
+
+    plans = plan_ranks(args.gpus, os.environ, share_gpu=args.share_gpu)
+    if plans:                                  # launcher: nothing below runs in this process, the GPU stays untouched
+        sys.exit(launch_ranks(plans))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.share_gpu:
         local_rank = 0
+    if world != max(args.gpus, 1) and "WORLD_SIZE" in os.environ and args.gpus > 1:
+        raise SystemExit(f"--gpus {args.gpus} disagrees with WORLD_SIZE={world}")
     use_dist = world > 1 or args.force_dist
+    if args.plan_only:
+        if use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo")
+            tot = torch.ones(1)
+            dist.all_reduce(tot)
+            assert int(tot) == world
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"plan_only": True, "n_gpus": world, "workload": args.workload, "local_rank": local_rank}), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -224,8 +283,10 @@ def main():
         ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)
         hbm_bound = (flops / max(nbytes, 1.0)) < ridge
         traffic = None
-        pmc = REPO / "profiles" / "r01_pmc_gemm_nt.json"
-        if pmc.exists() and args.workload == "cfg2" and B == 256 and args.dtype == "bf16":
+        # HBM traffic per launch of the dominant kernel comes from the separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE
+        # cannot share a pass, profiles/collect_r02.sh); the file records the commit-time kernel it was measured on.
+        pmc = REPO / "profiles" / f"r02_pmc_{args.workload}_{args.dtype}.json"
+        if pmc.exists() and B == 256:
             traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
         per_step = n_launch // (min(8, args.steps) if graphed is None else 4)
         if args.probe_dump:
@@ -259,7 +320,7 @@ def main():
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(kw, C, T)
+            out["cpu_baseline"] = cpu_baseline(kw, C, T, Bc=args.cpu_batch)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

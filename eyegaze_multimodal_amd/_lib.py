@@ -11,9 +11,9 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libeyegaze_hip.so"
 
-EG_F32, EG_BF16 = 0, 1
+EG_F32, EG_BF16, EG_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class EgError(RuntimeError):
@@ -30,7 +30,12 @@ def rowmap(row_stride: int, group_stride: int = 0, rows_per_group: int = 0) -> R
 
 class StepState(C.Structure):
     _fields_ = [("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32), ("lr", C.c_float), ("bias_corr1", C.c_float),
-                ("bias_corr2", C.c_float), ("grad_scale", C.c_float), ("clip_coef", C.c_float), ("grad_norm", C.c_float)]
+                ("bias_corr2", C.c_float), ("grad_scale", C.c_float), ("clip_coef", C.c_float), ("grad_norm", C.c_float),
+                ("loss_scale", C.c_float), ("found_inf", C.c_uint32), ("good_steps", C.c_uint32), ("opt_steps", C.c_uint32),
+                ("use_dev_t", C.c_uint32), ("skipped", C.c_uint32), ("scaler_on", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+STATE_WORDS = C.sizeof(StepState) // 4   # 16
 
 
 class GemmDesc(C.Structure):
@@ -105,6 +110,9 @@ SIGNATURES = {
     "eg_clip_coef": [_P, _I, _F, _P, _P],
     "eg_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P],
     "eg_fill_f32": [_P, _L, _F, _P],
+    "eg_adamw_group": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P],
+    "eg_set_step_state": [_P, _U, _U, _F, _F, _F, _F, _I, _F, _I, _P],
+    "eg_scaler_update": [_P, _F, _F, _I, _P],
     "eg_aux_symmetry": [_P, _P, _P, _P, _P, _I, _I, _P],
     "eg_aux_infonce": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P],
     "eg_aux_supcon": [_P, _P, _F, _P, _P, _P, _I, _I, _P],

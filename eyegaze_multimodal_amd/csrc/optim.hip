@@ -35,19 +35,56 @@ __global__ void clip_coef_kernel(const float* __restrict__ partial, int n, float
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const float norm = (float)sqrt(red[0]) * st->grad_scale;
+    const float ls = st->scaler_on ? st->loss_scale : 1.0f;
+    const float norm = (float)sqrt(red[0]) * (st->grad_scale / ls);
     st->grad_norm = norm;
     float coef = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.0f;
     st->clip_coef = fminf(coef, 1.0f);
+    st->found_inf = (st->scaler_on && !(fabsf(norm) <= 3.0e38f)) ? 1u : 0u;   // inf or NaN
+  }
+}
+
+__global__ void set_step_state_kernel(eg_step_state* st, uint32_t seed_lo, uint32_t seed_hi, float lr, float bc1, float bc2,
+                                      float grad_scale, int reset_scaler, float init_scale, int use_dev_t) {
+  st->seed_lo = seed_lo; st->seed_hi = seed_hi; st->lr = lr; st->bias_corr1 = bc1; st->bias_corr2 = bc2;
+  st->grad_scale = grad_scale; st->use_dev_t = (uint32_t)use_dev_t;
+  if (reset_scaler) {
+    st->scaler_on = reset_scaler == 1 ? 1u : 0u;
+    st->loss_scale = reset_scaler == 1 ? init_scale : 1.0f;
+    st->found_inf = 0u; st->good_steps = 0u; st->opt_steps = 0u; st->skipped = 0u;
+    st->clip_coef = 1.0f; st->grad_norm = 0.0f;
+  }
+}
+
+__global__ void scaler_update_kernel(eg_step_state* st, float growth, float backoff, int growth_interval) {
+  if (st->scaler_on && st->found_inf) {
+    st->loss_scale *= backoff;
+    st->good_steps = 0u;
+    st->skipped += 1u;
+    return;
+  }
+  st->opt_steps += 1u;
+  if (!st->scaler_on) return;
+  st->good_steps += 1u;
+  if ((int)st->good_steps >= growth_interval) {
+    st->loss_scale *= growth;
+    st->good_steps = 0u;
   }
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long long n,
-                                                    float beta1, float beta2, float eps, float wd,
+                                                    float beta1, float beta2, float eps, float wd, float lr_mult,
                                                     const eg_step_state* __restrict__ st) {
-  const float lr = st->lr, bc1 = st->bias_corr1, bc2s = sqrtf(st->bias_corr2);
-  const float gs = st->grad_scale * st->clip_coef;
+  if (st->scaler_on && st->found_inf) return;        // GradScaler.step: non-finite gradients -> no update at all
+  float bc1 = st->bias_corr1, bc2 = st->bias_corr2;
+  if (st->use_dev_t) {                               // skipped steps do not advance t: the device keeps the count
+    const float t = (float)(st->opt_steps + 1u);
+    bc1 = 1.0f - powf(beta1, t);
+    bc2 = 1.0f - powf(beta2, t);
+  }
+  const float lr = st->lr * lr_mult, bc2s = sqrtf(bc2);
+  const float gs = st->grad_scale * st->clip_coef / (st->scaler_on ? st->loss_scale : 1.0f);
   const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   const int cnt = (int)min(4ll, n - i);
@@ -97,14 +134,38 @@ extern "C" int eg_clip_coef(const float* partial, int nblk, float max_norm, eg_s
   return 0;
 }
 
-extern "C" int eg_adamw(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
-                        float weight_decay, const eg_step_state* state, void* stream) {
+extern "C" int eg_adamw_group(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                              float weight_decay, float lr_mult, const eg_step_state* state, void* stream) {
   EG_CHECK(p && g && m && v && state && n > 0, "eg_adamw: bad arguments");
   EG_CHECK(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "eg_adamw: alignment");
   const long long nt = (n + 3) / 4;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     (long long)n, beta1, beta2, eps, weight_decay, state);
+                     (long long)n, beta1, beta2, eps, weight_decay, lr_mult, state);
   EG_LAUNCH_CHECK("adamw");
+  return 0;
+}
+
+extern "C" int eg_adamw(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                        float weight_decay, const eg_step_state* state, void* stream) {
+  return eg_adamw_group(p, g, m, v, n, beta1, beta2, eps, weight_decay, 1.0f, state, stream);
+}
+
+extern "C" int eg_set_step_state(eg_step_state* state, uint32_t seed_lo, uint32_t seed_hi, float lr, float bias_corr1,
+                                 float bias_corr2, float grad_scale, int reset_scaler, float init_scale, int use_dev_t,
+                                 void* stream) {
+  EG_CHECK(state && (uintptr_t)state % 16 == 0, "eg_set_step_state: state must be a 16-B aligned device pointer");
+  EG_CHECK(reset_scaler >= 0 && reset_scaler <= 2, "eg_set_step_state: reset_scaler %d", reset_scaler);
+  EG_CHECK(reset_scaler != 1 || init_scale > 0.f, "eg_set_step_state: init_scale must be positive");
+  hipLaunchKernelGGL(set_step_state_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, seed_lo, seed_hi, lr, bias_corr1,
+                     bias_corr2, grad_scale, reset_scaler, init_scale, use_dev_t);
+  EG_LAUNCH_CHECK("set_step_state");
+  return 0;
+}
+
+extern "C" int eg_scaler_update(eg_step_state* state, float growth, float backoff, int growth_interval, void* stream) {
+  EG_CHECK(state && growth >= 1.f && backoff > 0.f && backoff <= 1.f && growth_interval > 0, "eg_scaler_update: bad arguments");
+  hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, growth, backoff, growth_interval);
+  EG_LAUNCH_CHECK("scaler_update");
   return 0;
 }
 

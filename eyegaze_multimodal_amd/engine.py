@@ -231,10 +231,9 @@ class Engine:
         self.a = a
         # backward temporaries (allocated lazily on the first backward)
         self.g: Dict[str, torch.Tensor] = {}
-        # step state: pinned host mirror -> device struct
-        self.state_host = torch.zeros(8, dtype=torch.int32).pin_memory() if self.device.type == "cuda" else torch.zeros(8, dtype=torch.int32)
-        self.state_dev = torch.zeros(8, dtype=torch.int32, device=self.device)
-        self.set_state(seed=0, lr=0.0, step=1, grad_scale=1.0)
+        # device-resident step state (eg_step_state); the host publishes a step's scalars as kernel arguments
+        self.state_dev = torch.zeros(L.STATE_WORDS, dtype=torch.int32, device=self.device)
+        self.set_state(seed=0, lr=0.0, step=1, grad_scale=1.0, reset_scaler=2)
 
     def _alloc_bwd(self):
         if self.g:
@@ -265,12 +264,16 @@ class Engine:
         self.g = g
 
     # ------------------------------------------------------------------------------------------
-    def set_state(self, seed: int, lr: float, step: int, grad_scale: float = 1.0, beta1=0.9, beta2=0.999):
+    def set_state(self, seed: int, lr: float, step: int, grad_scale: float = 1.0, beta1=0.9, beta2=0.999,
+                  reset_scaler: int = 0, init_scale: float = 65536.0, use_dev_t: bool = False):
+        """Publishes this step's host scalars.  They travel as kernel ARGUMENTS of a one-thread launch on the current
+        stream (eg_set_step_state), so the host may run any number of steps ahead: a queued step can never observe a later
+        step's seed / lr / bias corrections (a pinned staging buffer re-used per step could be overwritten before its copy ran).
+        reset_scaler: 0 keep the device's loss-scaling words, 1 enable dynamic loss scaling at init_scale, 2 disable."""
         seed = scramble_seed(seed)     # consecutive step seeds must not share their low / high words (common.h: eg_hash)
-        st = StepState(seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, lr, 1.0 - beta1 ** step, 1.0 - beta2 ** step,
-                       grad_scale, 1.0, 0.0)
-        C.memmove(self.state_host.data_ptr(), C.addressof(st), C.sizeof(st))
-        self.state_dev.copy_(self.state_host, non_blocking=True)
+        call("eg_set_step_state", self.state_dev.data_ptr(), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, float(lr),
+             1.0 - beta1 ** step, 1.0 - beta2 ** step, float(grad_scale), int(reset_scaler), float(init_scale),
+             int(bool(use_dev_t)), self._cur_stream())
 
     def read_state(self) -> StepState:
         host = self.state_dev.cpu()

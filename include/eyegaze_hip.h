@@ -30,8 +30,8 @@
 extern "C" {
 #endif
 
-#define EG_ABI_VERSION 2
-enum { EG_F32 = 0, EG_BF16 = 1 };
+#define EG_ABI_VERSION 3
+enum { EG_F32 = 0, EG_BF16 = 1, EG_F16 = 2 };
 enum { EG_ACT_NONE = 0, EG_ACT_RELU = 1, EG_ACT_GELU = 2 };
 
 int eg_abi_version(void);
@@ -48,8 +48,25 @@ typedef struct eg_step_state {
   float bias_corr2;          /* 1 - beta2^t */
   float grad_scale;          /* multiplies gradients before clipping (1/world_size for a summed all-reduce) */
   float clip_coef;           /* written by eg_clip_coef: min(1, max_norm/(norm+1e-6)) (T:221) */
-  float grad_norm;           /* written by eg_clip_coef: global L2 norm before clipping */
+  float grad_norm;           /* written by eg_clip_coef: global L2 norm before clipping (after un-scaling) */
+  /* dynamic loss scaling (fp16 path; torch.cuda.amp.GradScaler semantics, train_multimodal_fuzzy_fusion.py:435-472).
+   * These four words live on the device across steps; eg_set_step_state leaves them alone unless asked to reset. */
+  float loss_scale;          /* the loss gradient fed to backward is multiplied by this; eg_clip_coef divides it out */
+  uint32_t found_inf;        /* written by eg_clip_coef: 1 when the gradient norm is not finite -> eg_adamw skips the step */
+  uint32_t good_steps;       /* consecutive finite steps since the last change of loss_scale */
+  uint32_t opt_steps;        /* optimiser steps actually taken (skipped steps do not count); t of the bias corrections
+                                when use_dev_t != 0 */
+  uint32_t use_dev_t;        /* 0: bias_corr1/2 come from the host; 1: eg_adamw derives them from opt_steps + 1 */
+  uint32_t skipped;          /* total skipped steps */
+  uint32_t scaler_on;        /* 0: loss_scale is 1 and non-finite gradients are NOT intercepted (the reference's fp32 loop) */
+  uint32_t _pad;
 } eg_step_state;
+/* Publishes the host-side scalars of a step.  They travel as KERNEL ARGUMENTS (copied at launch), so a host that runs
+ * many steps ahead of the device can never overwrite a value a queued step still has to read.  reset_scaler: 0 leaves the
+ * loss-scaling words alone; 1 enables scaling (loss_scale = init_scale, scaler_on = 1); 2 disables it (loss_scale = 1,
+ * scaler_on = 0); 1 and 2 also zero found_inf / good_steps / opt_steps / skipped. */
+int eg_set_step_state(eg_step_state* state, uint32_t seed_lo, uint32_t seed_hi, float lr, float bias_corr1,
+                      float bias_corr2, float grad_scale, int reset_scaler, float init_scale, int use_dev_t, void* stream);
 
 /* Grouped row addressing: row r of a logical [M, *] matrix starts at element
  *   (r / rows_per_group) * group_stride + (r % rows_per_group) * row_stride
@@ -277,13 +294,23 @@ int eg_fuzzy_gate_bwd(const float* z_img, const float* z_eeg, const float* param
 /* ---------------------------------------------------------------------------------------------
  * Optimiser over flat fp32 buffers — clip_grad_norm_(1.0) + AdamW (T:221-222, T:401-405)
  *   eg_grad_sqnorm: partial[blk] = sum of squares;  eg_clip_coef: state->grad_norm / clip_coef (no host sync)
- *   eg_adamw: p *= 1-lr*wd; m,v update with g*grad_scale*clip_coef; p -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps)
+ *   eg_adamw: p *= 1-lr*wd; m,v update with g*grad_scale*clip_coef/loss_scale; p -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps);
+ *             the whole step is skipped when state->scaler_on && state->found_inf (GradScaler.step)
  * ------------------------------------------------------------------------------------------- */
 int eg_grad_sqnorm(const float* g, int64_t n, float* partial, int nblk, void* stream);
 int eg_clip_coef(const float* partial, int nblk, float max_norm, eg_step_state* state, void* stream);
 int eg_adamw(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
              float weight_decay, const eg_step_state* state, void* stream);
 int eg_fill_f32(float* p, int64_t n, float value, void* stream);
+/* per-group form of eg_adamw for optimisers with parameter groups (train_multimodal_fuzzy_fusion.py:395-432: one learning
+ * rate / weight decay per group): lr = state->lr * lr_mult. */
+int eg_adamw_group(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                   float weight_decay, float lr_mult, const eg_step_state* state, void* stream);
+/* GradScaler.update() on the device (train_multimodal_fuzzy_fusion.py:471-472): after the optimiser kernels of a step.
+ *   found_inf: loss_scale *= backoff, good_steps = 0, skipped += 1
+ *   else:      opt_steps += 1, good_steps += 1; good_steps == growth_interval -> loss_scale *= growth, good_steps = 0
+ * With scaler_on == 0 only opt_steps advances. */
+int eg_scaler_update(eg_step_state* state, float growth, float backoff, int growth_interval, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Inter-stream synchrony ("IBS") features — D:473-819 (connectivity matrices), D:178-470 (scalar variant)

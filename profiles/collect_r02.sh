@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round-2 evidence, collected on the MI355X box via gpurun (run from the repo root):  profiles/collect_r02.sh <tag> [workload] [dtype]
+# Kernel trace and PMC counters are separate runs; each --pmc pass carries one counter; the program follows `--` directly.
+set -e
+export TMPDIR=/tmp
+TAG=${1:-a}
+WL=${2:-cfg3}
+DT=${3:-bf16}
+KERNEL=${KERNEL:-gemm}
+O=gpurun_out/r02_${TAG}_${WL}_${DT}
+mkdir -p $O
+python bench.py --workload $WL --dtype $DT > $O/bench.json 2> $O/bench.err
+tail -c 600 $O/bench.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o run -- python3 bench.py --workload $WL --dtype $DT --no-cpu-baseline > $O/trace.log 2>&1
+python profiles/tools/kernel_summary.py $O/trace 121 > $O/kernel_summary.txt
+cp $(find $O/trace -name '*kernel_stats.csv' | head -n1) $O/kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 bench.py --workload $WL --dtype $DT --no-cpu-baseline --steps 6 --warmup 2 > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 bench.py --workload $WL --dtype $DT --no-cpu-baseline --steps 6 --warmup 2 > $O/pmc_write.log 2>&1
+python profiles/tools/pmc_by_kernel.py $O/pmc_fetch $O/pmc_write $O/pmc_by_kernel.json > $O/pmc_by_kernel.txt
+rm -rf $O/trace/*kernel_trace.csv $O/trace $O/pmc_fetch $O/pmc_write   # raw traces are large; the summaries above are what gets committed
+head -n 30 $O/kernel_summary.txt

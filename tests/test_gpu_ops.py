@@ -18,8 +18,8 @@ DT = {L.EG_BF16: torch.bfloat16, L.EG_F32: torch.float32}
 
 
 def dev_state(seed=1234, lr=1e-4, step=1, grad_scale=1.0):
-    st = StepState(seed & 0xFFFFFFFF, seed >> 32, lr, 1 - 0.9 ** step, 1 - 0.999 ** step, grad_scale, 1.0, 0.0)
-    host = torch.zeros(8, dtype=torch.int32)
+    st = StepState(seed & 0xFFFFFFFF, seed >> 32, lr, 1 - 0.9 ** step, 1 - 0.999 ** step, grad_scale, 1.0, 0.0, 1.0)
+    host = torch.zeros(L.STATE_WORDS, dtype=torch.int32)
     C.memmove(host.data_ptr(), C.addressof(st), C.sizeof(st))
     return host.to(DEV)
 
