@@ -5,6 +5,7 @@
 //   bf16: v_mfma_f32_16x16x32_bf16, K-tile 64      f32: v_mfma_f32_16x16x4_f32 (exact fmaf chain), K-tile 32
 // LDS rows are 128 B wide with a 16-B-chunk XOR swizzle so ds_read_b128 fragment reads are conflict-free.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -887,6 +888,8 @@ static int launch_gemm_row(const eg_gemm_desc* d, hipStream_t s) {
   return 0;
 }
 
+int eg_rs_gemm_try(const eg_gemm_desc* d, hipStream_t s);   // rsgemm.hip: register-stationary row-stream kernel (K == 256)
+
 extern "C" int eg_gemm_nt(const eg_gemm_desc* d, void* stream) {
   EG_CHECK(d && d->A && d->W && (d->C || d->ln_mode == 2), "eg_gemm_nt: null operand");
   EG_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "eg_gemm_nt: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -907,6 +910,12 @@ extern "C" int eg_gemm_nt(const eg_gemm_desc* d, void* stream) {
   EG_CHECK((long long)d->M * d->N < (1ll << 32), "eg_gemm_nt: M*N exceeds the 32-bit dropout index");
   EG_CHECK(((uintptr_t)d->A | (uintptr_t)d->W | (uintptr_t)d->C) % 16 == 0, "eg_gemm_nt: operands must be 16-B aligned");
   hipStream_t s = (hipStream_t)stream;
+  static const int use_rs = [] { const char* e = getenv("EYEGAZE_RS"); return e ? atoi(e) : 1; }();
+  if (use_rs) {
+    const int rc = eg_rs_gemm_try(d, s);
+    if (rc == 0) return 0;
+    if (rc != -1) return eg_fail("rs_gemm launch failed");
+  }
   if (d->ln_mode != 0 || d->row_tile) {
     EG_CHECK(d->ln_mode >= 0 && d->ln_mode <= 2, "eg_gemm_nt: ln_mode %d", d->ln_mode);
     EG_CHECK(d->N == RBN, "eg_gemm_nt: the row-complete tile (LayerNorm epilogue) needs N == %d, got %d", RBN, d->N);

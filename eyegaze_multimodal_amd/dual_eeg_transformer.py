@@ -273,6 +273,7 @@ class DualEEGTransformer(nn.Module):
     # ------------------------------------------------------------------------------------------
     def engine(self, B: int, T: int, device: torch.device) -> Engine:
         L.lib()  # raises when the HIP library is missing
+        device = torch.device(device)
         self._flat.ensure(device)
         key = (B, T, str(device), self._dtype)
         eng = self._engines.get(key)

@@ -1,0 +1,48 @@
+"""Diagnostic (manual, GPU box): eg_gemm_nt on the encoder's K = 256 shapes; EYEGAZE_RS=0/1 selects tiled / row-stream."""
+import sys, os, ctypes as C
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+from eyegaze_multimodal_amd import _lib as L
+from eyegaze_multimodal_amd._lib import GemmDesc, call, ptr, rowmap
+from tests.test_gpu_ops import dev_state
+dev = "cuda"
+
+
+def bench(M, N, K, residual=0, gate=0, act=0, drop=0.0, ln=0, reps=40):
+    td = torch.bfloat16
+    A = torch.randn(M, K, device=dev).to(td); W = (torch.randn(N, K, device=dev) * 0.1).to(td)
+    Cc = torch.zeros(M, N, device=dev, dtype=td); b = torch.randn(N, device=dev)
+    R = torch.randn(M, N, device=dev).to(td); st = dev_state()
+    d = GemmDesc(); d.A, d.W, d.C, d.bias = ptr(A), ptr(W), ptr(Cc), ptr(b)
+    d.residual = ptr(R) if residual else None; d.gate = ptr(R) if gate else None; d.state = ptr(st)
+    d.a, d.c = rowmap(K), rowmap(N); d.r = d.c; d.p = d.c
+    d.M, d.N, d.K, d.ldw, d.act, d.dtype = M, N, K, K, act, L.EG_BF16
+    d.drop1_p, d.drop1_site, d.gate_scale = drop, 5, 1.0
+    if ln:
+        gm = torch.ones(N, device=dev); Y = torch.zeros(M, N, device=dev, dtype=td); S = torch.zeros(M, 2, device=dev)
+        d.ln_mode, d.ln_gamma, d.ln_beta, d.ln_out, d.ln_stats = 1, ptr(gm), ptr(gm), ptr(Y), ptr(S)
+    for _ in range(5): call("eg_gemm_nt", C.byref(d), 0)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps): call("eg_gemm_nt", C.byref(d), 0)
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    byt = (M * K + N * K + M * N * (1 + (1 if (residual or gate) else 0) + (1 if ln else 0))) * 2
+    print(f"RS={os.environ.get('EYEGAZE_RS','1')} M={M:6d} N={N:5d} K={K:5d} res={residual} gate={gate} act={act} p={drop} ln={ln}: "
+          f"{best:7.1f} us  {2*M*N*K/best/1e6:7.1f} TF/s  {byt/best/1e6:5.2f} TB/s", flush=True)
+
+
+M = 33280
+bench(M, 768, 256)
+bench(M, 256, 256, residual=1, drop=0.1)
+bench(M, 256, 256, residual=1, drop=0.1, ln=1)
+bench(M, 1024, 256, act=1, drop=0.1)
+bench(M, 1024, 256, gate=1)
+bench(M, 256, 256)
+bench(M, 256, 256, residual=1)
+bench(4 * M, 256, 256, residual=1)
+bench(4 * M, 1024, 256, act=1, drop=0.1)

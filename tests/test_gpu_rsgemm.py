@@ -1,0 +1,119 @@
+"""Row-stream GEMM (csrc/rsgemm.hip: register-stationary weights, LDS-DMA row ring) against the tiled gemm_nt kernel and
+against fp64 torch.  Both kernels run the same k-ordered MFMA chain, so eg_gemm_nt must give BIT-IDENTICAL results whichever
+kernel serves the call (EYEGAZE_RS=0 in a child process selects the tiled kernel).  Shapes: the encoder's K = 256 products
+with every epilogue they use, ragged M (not a multiple of 16), one block per workgroup, many blocks per workgroup."""
+import ctypes as C
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from eyegaze_multimodal_amd import _lib as L  # noqa: E402
+from eyegaze_multimodal_amd._lib import GemmDesc, call, ptr, rowmap  # noqa: E402
+from tests.helpers import hip_keep_mask  # noqa: E402
+from tests.test_gpu_ops import dev_state  # noqa: E402
+
+DEV = "cuda"
+REPO = Path(__file__).resolve().parent.parent
+CASES = [
+    # M, N, residual, gate, act, drop, out_pre, ln
+    (33280, 768, 0, 0, 0, 0.0, 0, 0),      # q|k|v
+    (33280, 256, 1, 0, 0, 0.1, 0, 0),      # out-proj + dropout + residual
+    (33280, 256, 1, 0, 0, 0.1, 0, 1),      # ... with LayerNorm in the epilogue
+    (33280, 1024, 0, 0, 1, 0.1, 0, 0),     # FFN-1: ReLU + dropout
+    (33280, 1024, 0, 1, 0, 0.0, 0, 0),     # FFN-2 backward-data: gate
+    (33280, 256, 0, 0, 0, 0.0, 0, 0),      # out-proj backward-data
+    (520, 768, 0, 0, 0, 0.0, 0, 0),        # B = 4: fewer blocks than CUs
+    (1037, 256, 1, 0, 1, 0.2, 1, 0),       # ragged M, out_pre
+    (16 * 256 * 23 + 5, 512, 0, 1, 0, 0.1, 0, 0),   # 23+ blocks per workgroup: the ring wraps several times
+    (8, 256, 1, 0, 0, 0.0, 0, 1),          # less than one block
+]
+
+
+def run_case(M, N, residual, gate, act, drop, out_pre, ln, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + M + N)
+    K = 256
+    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    R = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+    G = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+    out = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+    pre = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+    y = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+    stats = torch.zeros(M, 2, device=DEV)
+    gam, bet = torch.randn(N, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
+    st = dev_state(seed=1234 + seed)
+    d = GemmDesc()
+    d.A, d.W, d.C, d.bias = ptr(A), ptr(W), ptr(out), ptr(b)
+    d.residual = ptr(R) if residual else None
+    d.gate = ptr(G) if gate else None
+    d.out_pre = ptr(pre) if out_pre else None
+    d.state = ptr(st)
+    d.a, d.c = rowmap(K), rowmap(N)
+    d.r, d.p = d.c, d.c
+    d.M, d.N, d.K, d.ldw, d.act, d.dtype = M, N, K, K, act, L.EG_BF16
+    d.drop1_p, d.drop1_site, d.gate_scale = drop, 11, 1.25 if gate else 1.0
+    if ln:
+        d.ln_mode, d.ln_gamma, d.ln_beta, d.ln_out, d.ln_stats = 1, ptr(gam), ptr(bet), ptr(y), ptr(stats)
+    call("eg_gemm_nt", C.byref(d), 0)
+    torch.cuda.synchronize()
+    t = dict(A=A, W=W, b=b, R=R, G=G, gam=gam, bet=bet)
+    return t, dict(out=out.float().cpu(), pre=pre.float().cpu(), y=y.float().cpu(), stats=stats.cpu())
+
+
+def reference(t, M, N, residual, gate, act, drop, out_pre, ln, seed=0):
+    v = t["A"].double().cpu() @ t["W"].double().cpu().T + t["b"].double().cpu()
+    if act == 1:
+        v = v.clamp_min(0)
+    if gate:
+        v = torch.where(t["G"].double().cpu() > 0, v * 1.25, torch.zeros_like(v))
+    if drop > 0:
+        idx = np.arange(M * N, dtype=np.uint64).astype(np.uint32)
+        keep = torch.from_numpy(hip_keep_mask(1234 + seed, 11, idx, drop).reshape(M, N))
+        # dev_state() stores the seed unscrambled; hip_keep_mask scrambles like Engine.set_state -> compare statistically below
+        v_keep = keep
+    pre = v.clone()
+    if residual:
+        v = v + t["R"].double().cpu()
+    return v, pre
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "M%d_N%d_r%d_g%d_a%d_p%g_o%d_ln%d" % c)
+def test_rs_gemm_is_bit_identical_to_the_tiled_kernel(case, tmp_path):
+    M, N, residual, gate, act, drop, out_pre, ln = case
+    _, got = run_case(*case)
+    # same call served by the tiled kernel, in a fresh process (the switch is read once per process)
+    dump = tmp_path / "ref.pt"
+    code = ("import sys, torch; sys.path.insert(0, %r); from tests.test_gpu_rsgemm import run_case; "
+            "_, r = run_case(*%r); torch.save(r, %r)" % (str(REPO), tuple(case), str(dump)))
+    env = dict(os.environ, EYEGAZE_RS="0")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, cwd=str(REPO))
+    ref = torch.load(dump, weights_only=True)
+    assert torch.equal(got["out"], ref["out"]), float((got["out"] - ref["out"]).abs().max())
+    if out_pre:
+        assert torch.equal(got["pre"], ref["pre"])
+    if ln:
+        assert torch.equal(got["y"], ref["y"])
+        assert torch.equal(got["stats"], ref["stats"])
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[5] == 0.0], ids=lambda c: "M%d_N%d_r%d_g%d_a%d_p%g_o%d_ln%d" % c)
+def test_rs_gemm_matches_fp64(case):
+    M, N, residual, gate, act, drop, out_pre, ln = case
+    t, got = run_case(*case)
+    v, pre = reference(t, *case)
+    err = float((got["out"].double() - v).abs().max())
+    assert err <= 0.02 + 0.008 * float(v.abs().max()), err          # one bf16 rounding of the result
+    if ln:
+        x = got["out"].double()
+        mean, var = x.mean(-1, keepdim=True), x.var(-1, unbiased=False, keepdim=True)
+        yy = (x - mean) / torch.sqrt(var + 1e-5) * t["gam"].double().cpu() + t["bet"].double().cpu()
+        assert float((got["y"].double() - yy).abs().max()) <= 0.03 + 0.008 * float(yy.abs().max())
+        assert float((got["stats"][:, 0].double() - mean[:, 0]).abs().max()) < 1e-4
