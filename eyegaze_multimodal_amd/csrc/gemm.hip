@@ -76,7 +76,15 @@ __device__ __forceinline__ void mma_ktile<float>(const char* bufA, const char* b
   }
 }
 
-template <typename T>
+// the activation is a template parameter: with a run-time `act` every element carries the branch tree of erff() inline
+template <int ACT>
+__device__ __forceinline__ float apply_act_t(float v) {
+  if (ACT == EG_ACT_RELU) return fmaxf(v, 0.f);
+  if (ACT == EG_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+  return v;
+}
+
+template <typename T, int ACT>
 __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmNT<T> p) {
   // 3 workgroups per CU: ONE 32 KiB LDS staging tile (the next K-tile waits in registers) and an epilogue that
   // passes the two 64-row halves of the tile through a 33 KiB fp32 LDS image one after the other.  The small-K
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmNT<T> p) {
         float v[8];
         load8(ct + row * CT_PITCH + ch * 8, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bv[j], p.act);
+        for (int j = 0; j < 8; ++j) v[j] = apply_act_t<ACT>(v[j] + bv[j]);
         const long long coff = row_off(p.c, m) + n;
         if (p.gate) {
           float gv[8];
@@ -846,12 +854,9 @@ static int launch_gemm_nt(const eg_gemm_desc* d, hipStream_t s) {
   p.gate_scale = d->gate_scale == 0.f ? 1.0f : d->gate_scale;
   p.seg_tiles = d->a_seg_len > 0 ? d->a_seg_len / (128 / (int)sizeof(T)) : 0;
   p.seg_stride_bytes = (long long)d->a_seg_stride * (long long)sizeof(T);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3(p.nblocks), dim3(256), NT_LDS_BYTES, s, p);
+  if (d->act == EG_ACT_RELU) hipLaunchKernelGGL((gemm_nt_kernel<T, EG_ACT_RELU>), dim3(p.nblocks), dim3(256), NT_LDS_BYTES, s, p);
+  else if (d->act == EG_ACT_GELU) hipLaunchKernelGGL((gemm_nt_kernel<T, EG_ACT_GELU>), dim3(p.nblocks), dim3(256), NT_LDS_BYTES, s, p);
+  else hipLaunchKernelGGL((gemm_nt_kernel<T, EG_ACT_NONE>), dim3(p.nblocks), dim3(256), NT_LDS_BYTES, s, p);
   EG_LAUNCH_CHECK("gemm_nt");
   return 0;
 }

@@ -2,39 +2,46 @@
 //   C[M, N] = epilogue(A[M, 256] * W[N, 256]^T)      q|k|v, out-proj, FFN-1 and their backward-data twins
 //
 // These products sit far below the MFMA ridge (FLOP/B ~ 100-200): the roofline that binds them is HBM, and with only
-// 130 rows per CU at the benchmark size a tiled kernel spends its life in load -> barrier -> MFMA -> barrier latency chains.
+// 130 rows per CU at the benchmark size a tiled kernel spends its life in load -> barrier -> MFMA -> barrier latency chains
+// while every 128x128 tile pulls 4 bytes through the CU's load path per byte it writes.
 // Design (gfx950):
-//   * weights are REGISTER-stationary: a 512-thread workgroup (8 waves, 2 per SIMD) owns a 256-column slice of W; wave w keeps
-//     its 32 columns x 256 k as MFMA operands in 64 VGPRs for the whole launch -- W costs no LDS bandwidth at all;
-//   * one workgroup per CU walks a contiguous range of 16-row blocks of A (ranges balanced to +-1 block, so all 256 CUs finish
-//     together whatever M is); row blocks arrive by LDS-DMA (global_load_lds, 16 B per lane) into a 7-deep ring, so ~56 KB of
-//     activation rows (and as many residual / gate rows) are in flight per CU at all times and HBM never idles behind a barrier;
-//   * the XOR swizzle of the ring lives on the DMA's per-lane SOURCE address (the LDS side of a DMA is lane-linear), the matching
-//     XOR on the fragment reads makes the ds_read_b128 conflict-free;
-//   * one raw s_barrier per row block; waits are counted s_waitcnt vmcnt(N) (loads, DMAs and stores share the counter in issue
-//     order, so the kernel keeps its own tally of issued vector-memory instructions);
-//   * the epilogue goes through a double-buffered fp32 LDS image so every global access is a whole 512-B row segment; with
-//     N == 256 a half-wave owns a complete row and LayerNorm (A:293) runs right there (ln_mode 1).
+//   * weights are REGISTER-stationary: a 512-thread workgroup (8 waves = 2 row blocks x 4 column groups, 2 waves per SIMD)
+//     owns a 256-column slice of W; a wave keeps its 64 columns x 256 k as MFMA operands in 128 VGPRs for the whole launch --
+//     W costs no LDS bandwidth and leaves L2 once per workgroup;
+//   * one workgroup per CU walks a contiguous range of 16-row blocks of A, two blocks (32 rows) per iteration; ranges are
+//     balanced to +-1 block so all CUs finish together whatever M is.  Rows arrive by LDS-DMA (global_load_lds, 16 B per lane)
+//     into a 4-pair ring three pairs ahead of their use, the residual / gate rows into a second ring two pairs ahead;
+//   * the XOR swizzle of the rings lives on the DMA's per-lane SOURCE address (the LDS side of a DMA is lane-linear); the
+//     matching XOR on the reads makes the ds_read_b128 (fragments) and ds_read_b64 (epilogue operand) conflict-free;
+//   * ONE raw s_barrier per 32 rows; waits are counted s_waitcnt vmcnt(N) -- loads, DMAs and stores share the counter in issue
+//     order, so the kernel keeps its own tally of issued vector-memory instructions, and row index clamping (never
+//     predication) keeps that tally exact;
+//   * the epilogue is wave-local: accumulators -> bias / ReLU / gate / dropout / residual in the MFMA layout -> a 2 KB
+//     wave-private LDS image -> 16-B stores that each cover 8 whole 128-B lines.  Waves 4-7 (the SIMD partners of waves 0-3)
+//     run half a step behind -- epilogue of pair t-1, then the MFMAs of pair t -- so one wave's matrix work sits beside its
+//     partner's vector / store work between two barriers.
 // Arithmetic is the same k-ordered MFMA chain as gemm_nt_kernel, so results are bit-identical to it.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int RS_R = 7;                     // ring depth (row blocks)
-constexpr int RS_BLK = 16 * 512;            // one row block: 16 rows x 256 16-bit elements
-constexpr int RS_SP = 260;                  // fp32 staging pitch (floats)
-constexpr int RS_STAGE = 16 * RS_SP * 4;    // one staging image
-constexpr int RS_LDS = 2 * RS_R * RS_BLK + 2 * RS_STAGE;   // 147,968 B
+constexpr int RS_RA = 4;                    // A ring depth (pairs of row blocks)
+constexpr int RS_RE = 4;                    // epilogue-operand ring depth (pairs)
+constexpr int RS_PAIR = 32 * 512;           // one pair: 32 rows x 256 16-bit elements
+constexpr int RS_TP = 144;                  // pitch (bytes) of the wave-private output image: 64 x 16-bit + 16
+constexpr int RS_TW = 16 * RS_TP;           // one wave's image: 16 rows
+constexpr int RS_LDS = (RS_RA + RS_RE) * RS_PAIR + 8 * RS_TW;   // 149,504 B
 
 struct RsGemm {
   const bf16_t* A; const bf16_t* W; bf16_t* C; const float* bias; const bf16_t* E; bf16_t* out_pre;
   const eg_step_state* st;
-  long long lda, ldc, lde, ldp;             // row strides (elements)
-  int M, N, ldw, act, e_mode;               // e_mode: 0 none, 1 residual (added last), 2 gate (ReLU backward)
+  int lda, ldc, lde, ldp;                   // row strides (elements); M * stride < 2^32 is checked by the host
+  int M, N, ldw;
   int nblk, groups, ns;                     // 16-row blocks, row groups, 256-column slices
   DropCfg d1, d2;
   float gate_scale;
-  int ln_mode; const float* gamma; const float* beta; float* stats; bf16_t* ln_out;
+  int dbg;                                  // diagnostic bits (timing experiments only, results are wrong when set)
 };
 
 __device__ __forceinline__ void dma16(const char* g, char* l) {
@@ -42,213 +49,242 @@ __device__ __forceinline__ void dma16(const char* g, char* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the field is an immediate); n is clamped DOWN to 31 = waits for more
-#define RS_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the field is an immediate); n is rounded DOWN (= waits for more)
 __device__ __forceinline__ void wait_vmcnt(int n) {
-  n = __builtin_amdgcn_readfirstlane(n);
+  n = __builtin_amdgcn_readfirstlane(n) >> 1;      // even counts only: at most one more instruction is waited for
   switch (n) {
-    RS_W(0) RS_W(1) RS_W(2) RS_W(3) RS_W(4) RS_W(5) RS_W(6) RS_W(7) RS_W(8) RS_W(9) RS_W(10) RS_W(11) RS_W(12) RS_W(13)
-    RS_W(14) RS_W(15) RS_W(16) RS_W(17) RS_W(18) RS_W(19) RS_W(20) RS_W(21) RS_W(22) RS_W(23) RS_W(24) RS_W(25) RS_W(26)
-    RS_W(27) RS_W(28) RS_W(29) RS_W(30)
-    default: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
   }
 }
-#undef RS_W
 
-__device__ __forceinline__ float rs_act(float v, int act) {
-  if (act == EG_ACT_RELU) return fmaxf(v, 0.f);
-  if (act == EG_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-  return v;
-}
-__device__ __forceinline__ float rs_half_sum32(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// 4 floats -> 4 bf16 (two packed converts)
+__device__ __forceinline__ u32x2 rs_pack4(const float v[4]) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  const bf16x2 lo = __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2);
+  const bf16x2 hi = __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2);
+  u32x2 o;
+  o[0] = __builtin_bit_cast(uint32_t, lo);
+  o[1] = __builtin_bit_cast(uint32_t, hi);
+  return o;
 }
 
-template <int EMODE, int LN>
+// EMODE: 0 no epilogue operand, 1 residual (added last), 2 gate (ReLU backward: zero where gate <= 0)
+// RELU:  ReLU on acc + bias;  DROP: the dropout sites of the descriptor are live (each still checks its own threshold)
+template <int EMODE, int RELU, int DROP>
 __global__ __launch_bounds__(512, 2) void rs_gemm_kernel(RsGemm p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ringA = smem;
-  char* const ringE = smem + RS_R * RS_BLK;
-  float* const stage = (float*)(smem + 2 * RS_R * RS_BLK);
+  char* const ringE = smem + RS_RA * RS_PAIR;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;                   // row block of the pair, 64-column group of the slice
+  const bool late = wm == 1;                                 // waves 4-7 run their epilogues half a step behind (SIMD partners)
   const int l15 = lane & 15, g4 = lane >> 4;
+  char* const timg = smem + (RS_RA + RS_RE) * RS_PAIR + wave * RS_TW;
 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);          // neighbours (same rows, other column slices) share an XCD / L2
   const int rg = bid / p.ns, slice = bid - rg * p.ns;
   const int b0 = (int)((long long)rg * p.nblk / p.groups);
   const int nb = (int)((long long)(rg + 1) * p.nblk / p.groups) - b0;
+  const int npairs = (nb + 1) >> 1;
   const int n0 = slice * 256;
+  const int row0 = b0 * 16;
 
-  // ---- DMA source addressing: this lane moves 16 B of row (2*wave + lane/32) of every block; chunk position pos = lane%32 of
-  //      the LDS row holds global chunk pos ^ (row & 15) (A ring) or pos (E ring) ----
-  const int drow = 2 * wave + (lane >> 5), dpos = lane & 31;
-  const int dqA = dpos ^ (drow & 15);
+  // ---- DMA addressing: per pair a wave moves rows 4w .. 4w+3 (two instructions of 2 rows x 512 B); LDS position `pos` of
+  //      row r holds global 16-B chunk pos ^ (r & 15) ----
+  const int dpos = lane & 31;
   int vm_issued = 0;                                         // vector-memory instructions this wave has issued so far
-  int mark[RS_R];                                            // vm_issued right after the last DMA of the block in ring slot u
+  auto issueA = [&](int pair, int slot) {
 #pragma unroll
-  for (int u = 0; u < RS_R; ++u) mark[u] = 0;
-
-  auto issueA = [&](int item, int slot) {
-    const int row = min((b0 + item) * 16 + drow, p.M - 1);
-    dma16((const char*)(p.A + (long long)row * p.lda) + dqA * 16, ringA + slot * RS_BLK + wave * 1024);
-    vm_issued += 1;
-  };
-  auto issueE = [&](int item, int slot) {
-    const int row = min((b0 + item) * 16 + drow, p.M - 1);
-    dma16((const char*)(p.E + (long long)row * p.lde + n0) + dpos * 16, ringE + slot * RS_BLK + wave * 1024);
-    vm_issued += 1;
-  };
-
-  // ---- prologue: two row blocks (and their epilogue operands) first, then the weights (L2 hits), then the rest of the ring.
-  //      The first MFMA needs the weights, and a wait for an ordinary load also drains every DMA issued before it, so only the
-  //      blocks the first two iterations consume are issued ahead of the weight loads. ----
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-    if (j < nb) {
-      issueA(j, j);
-      if (EMODE) issueE(j, j);
+    for (int i = 0; i < 2; ++i) {
+      const int r = 4 * wave + 2 * i + (lane >> 5);          // row within the pair
+      const int row = min(row0 + pair * 32 + r, p.M - 1);
+      dma16((const char*)(p.A + (size_t)((uint32_t)row * (uint32_t)p.lda)) + ((dpos ^ (r & 15)) << 4),
+            ringA + slot * RS_PAIR + (4 * wave + 2 * i) * 512);
     }
+    vm_issued += 2;
+  };
+  auto issueE = [&](int pair, int slot) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = 4 * wave + 2 * i + (lane >> 5);
+      const int row = min(row0 + pair * 32 + r, p.M - 1);
+      dma16((const char*)(p.E + (size_t)((uint32_t)row * (uint32_t)p.lde) + n0) + ((dpos ^ (r & 15)) << 4),
+            ringE + slot * RS_PAIR + (4 * wave + 2 * i) * 512);
+    }
+    vm_issued += 2;
+  };
+
+  // ---- prologue: the first pair goes out before the weights (the first MFMA needs both; a wait for an ordinary load also
+  //      drains every DMA issued before it, so the rest of the ring is issued after that wait) ----
+  if (npairs > 0) {
+    issueA(0, 0);
+    if (EMODE) issueE(0, 0);
+  }
   asm volatile("" ::: "memory");
 
-  // ---- register-stationary weights: wave w owns columns n0 + 32w .. +31 ----
-  bf16x8 wf[2][8];
+  // register-stationary weights: this wave's 64 columns as MFMA A-operands (rows of W)
+  bf16x8 wf[4][8];
   {
-    const bf16_t* wrow = p.W + (long long)(n0 + 32 * wave + l15) * p.ldw + 8 * g4;
+    const bf16_t* wrow = p.W + (size_t)(n0 + 64 * wn + l15) * (size_t)p.ldw + 8 * g4;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int s = 0; s < 8; ++s) wf[j][s] = *(const bf16x8*)(wrow + (long long)(16 * j) * p.ldw + 32 * s);
+      for (int s = 0; s < 8; ++s) wf[j][s] = *(const bf16x8*)(wrow + (size_t)(16 * j) * (size_t)p.ldw + 32 * s);
   }
-
-  // ---- per-thread epilogue constants: thread owns row (tid/32) of a block and 8 consecutive columns ----
-  const int er = tid >> 5, ec = tid & 31;
-  const int n = n0 + ec * 8;
-  float bv[8], gam[8], bet[8];
+  // per-lane epilogue constants: accumulator register q of tile j is column n0 + 64wn + 16j + 4*g4 + q of row l15
+  const int ncol = n0 + 64 * wn + 4 * g4;
+  float bv[4][4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { bv[j] = 0.f; gam[j] = 1.f; bet[j] = 0.f; }
-  if (p.bias) load8(p.bias + n, bv);
-  if (LN) { load8(p.gamma + n, gam); load8(p.beta + n, bet); }
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[j][q] = 0.f;
+    if (p.bias) load4(p.bias + ncol + 16 * j, bv[j]);
+  }
   uint32_t seed_lo = 0, seed_hi = 0;
-  if (p.d1.thresh | p.d2.thresh) { seed_lo = p.st->seed_lo; seed_hi = p.st->seed_hi; }
+  if (DROP) { seed_lo = p.st->seed_lo; seed_hi = p.st->seed_hi; }
 
-  // everything issued so far must have landed (weights in registers, blocks 0 and 1 in the ring) ...
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // weights in registers, pair 0 in the ring (this wave's part)
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(wf[j][s]));
-  // ... then the rest of the ring goes in flight: blocks 2..R-2, epilogue operands 2..R-3; the tally starts here
+  // the rest of the rings goes in flight (A: pairs 1, 2; epilogue operand: pair 1); the tally of issued instructions starts here
   vm_issued = 0;
-#pragma unroll
-  for (int j = 2; j < RS_R - 1; ++j)
-    if (j < nb) {
-      issueA(j, j);
-      mark[j] = vm_issued;
-    }
-  if (EMODE) {
-#pragma unroll
-    for (int j = 2; j < RS_R - 2; ++j)
-      if (j < nb) {
-        issueE(j, j);
-        mark[j] = vm_issued;
-      }
+  if (1 < npairs) {
+    issueA(1, 1);
+    if (EMODE) issueE(1, 1);
   }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // blocks 0 and 1 are visible to every wave
+  const int mark_a = vm_issued;
+  if (2 < npairs) issueA(2, 2);
+  int mkA2 = mark_a, mkA1 = vm_issued, mkE1 = mark_a;        // tallies right after the request of pair t+1 (A) / t+2 (A) / t+1 (E)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // pair 0 is visible to every wave
 
-  for (int t0 = 0; t0 < nb; t0 += RS_R) {
+  f32x4 acc[4];
+  // epilogue of this wave's block of one pair, straight from the accumulators (wave-local)
+  auto epilogue = [&](int pair) {
+    if (2 * pair + wm >= nb) return;                         // the odd tail of the range has no second block
+    const int slotE = pair % RS_RE;
+    const int r = 16 * wm + l15;                             // row within the pair (MFMA layout)
+    const uint32_t mrow = (uint32_t)min(row0 + pair * 32 + r, p.M - 1);
+    const uint32_t drow = mrow * (uint32_t)p.N;
+    // rows this lane stores after the transposition: lane/8 and lane/8 + 8 of the block, 16 B at column 8*(lane%8)
+    const int sr = lane >> 3, sc = lane & 7;
+    const uint32_t m0 = (uint32_t)min(row0 + pair * 32 + 16 * wm + sr, p.M - 1);
+    const uint32_t m1 = (uint32_t)min(row0 + pair * 32 + 16 * wm + sr + 8, p.M - 1);
+    float v[4][4];
 #pragma unroll
-    for (int u = 0; u < RS_R; ++u) {
-      const int t = t0 + u;
-      if (t >= nb) break;
-      // -- keep the rings full: block t+R-1 goes into the slot block t-1 has just left; the epilogue operand trails by one --
-      const int slotAn = (u + RS_R - 1) % RS_R, slotEn = (u + RS_R - 2) % RS_R;
-      if (t + RS_R - 1 < nb) {
-        issueA(t + RS_R - 1, slotAn);
-        mark[slotAn] = vm_issued;
+    for (int j = 0; j < 4; ++j) {
+      const int n = ncol + 16 * j;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[j][q] = acc[j][q] + bv[j][q];
+        if (RELU) v[j][q] = fmaxf(v[j][q], 0.f);
       }
-      if (EMODE && t + RS_R - 2 < nb) {
-        issueE(t + RS_R - 2, slotEn);
-        mark[slotEn] = vm_issued;
+      if (EMODE == 2) {
+        float ev[4];
+        const int ch = (8 * wn + 2 * j + (g4 >> 1)) ^ (r & 15);
+        load4((const bf16_t*)(ringE + slotE * RS_PAIR + r * 512 + (ch << 4) + ((g4 & 1) << 3)), ev);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[j][q] = ev[q] > 0.f ? v[j][q] * p.gate_scale : 0.f;
       }
-      asm volatile("" ::: "memory");
-      // -- fragments of block t (swizzled rows), 16 MFMAs: D[n][m] = sum_k W[n][k] X[m][k] --
-      const char* ab = ringA + u * RS_BLK + l15 * 512;
-      bf16x8 xf[8];
+      if (DROP) {
+        const uint32_t idx = drow + (uint32_t)n;
+        eg_dropout_run<4>(v[j], p.d1, seed_lo, seed_hi, idx);
+        eg_dropout_run<4>(v[j], p.d2, seed_lo, seed_hi, idx);
+      }
+    }
+    const bool nostore = p.dbg & 1;
+    if (p.out_pre) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(u32x2*)(timg + l15 * RS_TP + (16 * j + 4 * g4) * 2) = rs_pack4(v[j]);
+      const u32x4 o0 = *(const u32x4*)(timg + sr * RS_TP + sc * 16);
+      const u32x4 o1 = *(const u32x4*)(timg + (sr + 8) * RS_TP + sc * 16);
+      if (!nostore) {
+        *(u32x4*)(p.out_pre + (size_t)(m0 * (uint32_t)p.ldp) + n0 + 64 * wn + 8 * sc) = o0;
+        *(u32x4*)(p.out_pre + (size_t)(m1 * (uint32_t)p.ldp) + n0 + 64 * wn + 8 * sc) = o1;
+        vm_issued += 2;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (EMODE == 1) {
+        float ev[4];
+        const int ch = (8 * wn + 2 * j + (g4 >> 1)) ^ (r & 15);
+        load4((const bf16_t*)(ringE + slotE * RS_PAIR + r * 512 + (ch << 4) + ((g4 & 1) << 3)), ev);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[j][q] += ev[q];
+      }
+      *(u32x2*)(timg + l15 * RS_TP + (16 * j + 4 * g4) * 2) = rs_pack4(v[j]);
+    }
+    const u32x4 o0 = *(const u32x4*)(timg + sr * RS_TP + sc * 16);
+    const u32x4 o1 = *(const u32x4*)(timg + (sr + 8) * RS_TP + sc * 16);
+    if (!nostore) {
+      *(u32x4*)(p.C + (size_t)(m0 * (uint32_t)p.ldc) + n0 + 64 * wn + 8 * sc) = o0;
+      *(u32x4*)(p.C + (size_t)(m1 * (uint32_t)p.ldc) + n0 + 64 * wn + 8 * sc) = o1;
+      vm_issued += 2;
+    } else {
+      asm volatile("" :: "v"(o0), "v"(o1));
+    }
+  };
+
+  int slotA = 0;
+  for (int t = 0; t < npairs; ++t) {
+    // -- keep the rings full: A pair t+3 goes into the slot pair t-1 has left, E pair t+2 into the slot pair t-2 has left --
+    if (!(p.dbg & 8)) {
+      if (t + 3 < npairs) issueA(t + 3, (t + 3) % RS_RA);
+      if (EMODE && t + 2 < npairs) issueE(t + 2, (t + 2) % RS_RE);
+    }
+    const int mk0 = vm_issued;
+    asm volatile("" ::: "memory");
+    if (late && t > 0) epilogue(t - 1);
+    asm volatile("" ::: "memory");
+    // -- fragments of this wave's block (swizzled rows), 32 MFMAs: D[n][m] = sum_k W[n][k] X[m][k] --
+    bf16x8 xf[8];
+    {
+      const char* ab = ringA + slotA * RS_PAIR + (16 * wm + l15) * 512;
 #pragma unroll
       for (int s = 0; s < 8; ++s) xf[s] = *(const bf16x8*)(ab + (((4 * s + g4) ^ l15) << 4));
-      f32x4 acc[2];
-      acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][s], xf[s], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][s], xf[s], acc[1], 0, 0, 0);
-      }
-      float* const sb = stage + ((t & 1) ? 16 * RS_SP : 0);
-      *(f32x4*)(sb + l15 * RS_SP + 32 * wave + 4 * g4) = acc[0];
-      *(f32x4*)(sb + l15 * RS_SP + 32 * wave + 16 + 4 * g4) = acc[1];
-      // -- block t+1 (and its epilogue operand) must have landed before the barrier that publishes it --
-      if (t + 1 < nb) wait_vmcnt(vm_issued - mark[(u + 1) % RS_R]);
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      // -- epilogue of block t: whole rows, 16 B per lane --
-      const int m = min((b0 + t) * 16 + er, p.M - 1);
-      float v[8];
-      load8(sb + er * RS_SP + ec * 8, v);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = rs_act(v[j] + bv[j], p.act);
-      u32x4 eraw = {0u, 0u, 0u, 0u};
-      if (EMODE) eraw = *(const u32x4*)(ringE + u * RS_BLK + er * 512 + ec * 16);
-      if (EMODE == 2) {
-        float gv[8];
-        load8((const bf16_t*)&eraw, gv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gv[j] > 0.f ? v[j] * p.gate_scale : 0.f;
-      }
-      if (p.d1.thresh | p.d2.thresh) {
-        const uint32_t idx = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
-        eg_dropout_run<8>(v, p.d1, seed_lo, seed_hi, idx);
-        eg_dropout_run<8>(v, p.d2, seed_lo, seed_hi, idx);
-      }
-      asm volatile("" ::: "memory");
-      if (p.out_pre) {
-        store8(p.out_pre + (long long)m * p.ldp + n, v);
-        vm_issued += 1;
-      }
-      if (EMODE == 1) {
-        float rv[8];
-        load8((const bf16_t*)&eraw, rv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += rv[j];
-      }
-      store8(p.C + (long long)m * p.ldc + n, v);
-      vm_issued += 1;
-      if (LN) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = bf2f(f2bf(v[j]));   // normalise exactly what was stored
-        float s1 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s1 += v[j];
-        const float mean = rs_half_sum32(s1) * (1.0f / 256.f);
-        float s2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float dlt = v[j] - mean; s2 += dlt * dlt; }
-        const float rstd = rsqrtf(rs_half_sum32(s2) * (1.0f / 256.f) + 1e-5f);
-        float y[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = (v[j] - mean) * rstd * gam[j] + bet[j];
-        store8(p.ln_out + (long long)m * 256 + n, y);
-        vm_issued += 1;
-        if (ec == 0) {                       // not counted: a predicated 8-B store (under-counting only waits longer)
-          p.stats[2 * (long long)m] = mean;
-          p.stats[2 * (long long)m + 1] = rstd;
-        }
-      }
-      asm volatile("" ::: "memory");
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!(p.dbg & 2)) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], xf[s], acc[j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(xf[s]));
+    }
+    asm volatile("" ::: "memory");
+    if (!late) epilogue(t);
+    asm volatile("" ::: "memory");
+    // -- pair t+1 (and its epilogue operand) must have landed before the barrier that publishes it --
+    if (t + 1 < npairs && !(p.dbg & 4)) wait_vmcnt(vm_issued - (EMODE ? mkE1 : mkA2));
+    if (!(p.dbg & 16)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    mkA2 = mkA1;
+    mkA1 = mk0;
+    mkE1 = mk0;
+    slotA = slotA + 1 == RS_RA ? 0 : slotA + 1;
   }
+  if (late && npairs > 0) epilogue(npairs - 1);
 }
 
 }  // namespace
@@ -257,11 +293,15 @@ __global__ __launch_bounds__(512, 2) void rs_gemm_kernel(RsGemm p) {
 int eg_rs_gemm_try(const eg_gemm_desc* d, hipStream_t s) {
   if (d->dtype != EG_BF16 || d->K != 256 || d->N % 256 != 0 || d->ldw != 256) return -1;
   if (d->a.rows_per_group || d->c.rows_per_group || d->r.rows_per_group || d->p.rows_per_group) return -1;
-  if (d->a_seg_len || d->ln_mode == 2 || d->row_tile) return -1;
+  if (d->a_seg_len || d->ln_mode || d->row_tile || d->act == EG_ACT_GELU) return -1;
   if (d->residual && d->gate) return -1;
-  if (d->ln_mode == 1 && d->N != 256) return -1;
   if (!d->C) return -1;
   if (d->a.row_stride % 8 || d->c.row_stride % 8 || (d->residual && d->r.row_stride % 8) || (d->out_pre && d->p.row_stride % 8)) return -1;
+  {
+    const long long lim = 1ll << 32, M = d->M;
+    if (M * d->a.row_stride >= lim || M * d->c.row_stride >= lim || (d->residual && M * d->r.row_stride >= lim) ||
+        (d->out_pre && M * d->p.row_stride >= lim)) return -1;
+  }
   if (((uintptr_t)d->A | (uintptr_t)d->W | (uintptr_t)d->C | (uintptr_t)d->residual | (uintptr_t)d->gate | (uintptr_t)d->out_pre) % 16) return -1;
   static int cus = 0;
   if (!cus) {
@@ -274,10 +314,10 @@ int eg_rs_gemm_try(const eg_gemm_desc* d, hipStream_t s) {
   p.A = (const bf16_t*)d->A; p.W = (const bf16_t*)d->W; p.C = (bf16_t*)d->C; p.bias = d->bias;
   p.E = (const bf16_t*)(d->residual ? d->residual : d->gate);
   p.out_pre = (bf16_t*)d->out_pre; p.st = d->state;
-  p.lda = d->a.row_stride; p.ldc = d->c.row_stride; p.lde = d->residual ? d->r.row_stride : d->c.row_stride;
-  p.ldp = d->p.row_stride;
-  p.M = d->M; p.N = d->N; p.ldw = d->ldw; p.act = d->act;
-  p.e_mode = d->residual ? 1 : (d->gate ? 2 : 0);
+  p.lda = (int)d->a.row_stride; p.ldc = (int)d->c.row_stride; p.lde = (int)(d->residual ? d->r.row_stride : d->c.row_stride);
+  p.ldp = (int)d->p.row_stride;
+  p.M = d->M; p.N = d->N; p.ldw = d->ldw;
+  const int e_mode = d->residual ? 1 : (d->gate ? 2 : 0);
   p.nblk = (d->M + 15) / 16;
   p.ns = d->N / 256;
   p.groups = cus / p.ns > 0 ? cus / p.ns : 1;
@@ -285,22 +325,27 @@ int eg_rs_gemm_try(const eg_gemm_desc* d, hipStream_t s) {
   p.d1 = make_drop(d->drop1_p, d->drop1_site);
   p.d2 = make_drop(d->drop2_p, d->drop2_site);
   p.gate_scale = d->gate_scale == 0.f ? 1.0f : d->gate_scale;
-  p.ln_mode = d->ln_mode; p.gamma = d->ln_gamma; p.beta = d->ln_beta; p.stats = d->ln_stats; p.ln_out = (bf16_t*)d->ln_out;
+  static const int dbg = [] { const char* e = getenv("EYEGAZE_RS_DBG"); return e ? atoi(e) : 0; }();
+  p.dbg = dbg;
   const dim3 grid(p.groups * p.ns), blk(512);
-#define RS_LAUNCH(E_, L_)                                                                                              \
+#define RS_LAUNCH(E_, R_, D_)                                                                                          \
   do {                                                                                                                 \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      hipFuncSetAttribute((const void*)rs_gemm_kernel<E_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);    \
+      (void)hipFuncSetAttribute((const void*)rs_gemm_kernel<E_, R_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                RS_LDS);                                                                               \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((rs_gemm_kernel<E_, L_>), grid, blk, RS_LDS, s, p);                                             \
+    hipLaunchKernelGGL((rs_gemm_kernel<E_, R_, D_>), grid, blk, RS_LDS, s, p);                                         \
   } while (0)
-  if (p.ln_mode == 1) {
-    if (p.e_mode == 1) RS_LAUNCH(1, 1); else if (p.e_mode == 2) RS_LAUNCH(2, 1); else RS_LAUNCH(0, 1);
-  } else {
-    if (p.e_mode == 1) RS_LAUNCH(1, 0); else if (p.e_mode == 2) RS_LAUNCH(2, 0); else RS_LAUNCH(0, 0);
-  }
+#define RS_PICK(E_)                                                                                                    \
+  do {                                                                                                                 \
+    if (relu) { if (drop) RS_LAUNCH(E_, 1, 1); else RS_LAUNCH(E_, 1, 0); }                                             \
+    else      { if (drop) RS_LAUNCH(E_, 0, 1); else RS_LAUNCH(E_, 0, 0); }                                             \
+  } while (0)
+  const bool relu = d->act == EG_ACT_RELU, drop = (p.d1.thresh | p.d2.thresh) != 0;
+  if (e_mode == 1) RS_PICK(1); else if (e_mode == 2) RS_PICK(2); else RS_PICK(0);
+#undef RS_PICK
 #undef RS_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -24,11 +24,22 @@ def bench(M, N, K, residual=0, gate=0, act=0, drop=0.0, ln=0, reps=40):
         d.ln_mode, d.ln_gamma, d.ln_beta, d.ln_out, d.ln_stats = 1, ptr(gm), ptr(gm), ptr(Y), ptr(S)
     for _ in range(5): call("eg_gemm_nt", C.byref(d), 0)
     torch.cuda.synchronize()
+    # the launches are replayed from a captured graph: the Python / ctypes launch path costs more host time per call than
+    # the short products take on the GPU
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        g.capture_begin()
+        for _ in range(reps): call("eg_gemm_nt", C.byref(d), side.cuda_stream)
+        g.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay(); torch.cuda.synchronize()
     best = 1e9
-    for _ in range(3):
+    for _ in range(4):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(reps): call("eg_gemm_nt", C.byref(d), 0)
+        g.replay()
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
     byt = (M * K + N * K + M * N * (1 + (1 if (residual or gate) else 0) + (1 if ln else 0))) * 2
@@ -37,6 +48,12 @@ def bench(M, N, K, residual=0, gate=0, act=0, drop=0.0, ln=0, reps=40):
 
 
 M = 33280
+if os.environ.get("RS_SHORT"):
+    bench(M, 768, 256)
+    bench(M, 1024, 256, act=1, drop=0.1)
+    bench(M, 256, 256, residual=1)
+    bench(4 * M, 256, 256, residual=1)
+    sys.exit(0)
 bench(M, 768, 256)
 bench(M, 256, 256, residual=1, drop=0.1)
 bench(M, 256, 256, residual=1, drop=0.1, ln=1)
