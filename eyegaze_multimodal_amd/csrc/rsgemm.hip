@@ -5,9 +5,9 @@
 // 130 rows per CU at the benchmark size a tiled kernel spends its life in load -> barrier -> MFMA -> barrier latency chains
 // while every 128x128 tile pulls 4 bytes through the CU's load path per byte it writes.
 // Design (gfx950):
-//   * weights are REGISTER-stationary: a 512-thread workgroup (8 waves = 2 row blocks x 4 column groups, 2 waves per SIMD)
-//     owns a 256-column slice of W; a wave keeps its 64 columns x 256 k as MFMA operands in 128 VGPRs for the whole launch --
-//     W costs no LDS bandwidth and leaves L2 once per workgroup;
+//   * weights are REGISTER-stationary: a 512-thread workgroup (8 waves, 2 per SIMD) owns a 256-column slice of W; wave w keeps
+//     its 32 columns x 256 k as MFMA operands in 64 VGPRs for the whole launch -- W costs no LDS bandwidth and leaves L2 once
+//     per workgroup;
 //   * one workgroup per CU walks a contiguous range of 16-row blocks of A, two blocks (32 rows) per iteration; ranges are
 //     balanced to +-1 block so all CUs finish together whatever M is.  Rows arrive by LDS-DMA (global_load_lds, 16 B per lane)
 //     into a 4-pair ring three pairs ahead of their use, the residual / gate rows into a second ring two pairs ahead;
@@ -16,10 +16,11 @@
 //   * ONE raw s_barrier per 32 rows; waits are counted s_waitcnt vmcnt(N) -- loads, DMAs and stores share the counter in issue
 //     order, so the kernel keeps its own tally of issued vector-memory instructions, and row index clamping (never
 //     predication) keeps that tally exact;
-//   * the epilogue is wave-local: accumulators -> bias / ReLU / gate / dropout / residual in the MFMA layout -> a 2 KB
-//     wave-private LDS image -> 16-B stores that each cover 8 whole 128-B lines.  Waves 4-7 (the SIMD partners of waves 0-3)
-//     run half a step behind -- epilogue of pair t-1, then the MFMAs of pair t -- so one wave's matrix work sits beside its
-//     partner's vector / store work between two barriers.
+//   * the epilogue is wave-local: accumulators -> bias / ReLU / gate / dropout / residual in the MFMA layout -> a 2.5 KB
+//     wave-private LDS image -> 16-B stores (16 rows x 64 B per instruction);
+//   * software pipeline: between two barriers a wave runs the MFMAs of pair t and the epilogue of pair t-1 (two accumulator
+//     sets); waves 4-7 (the SIMD partners of waves 0-3) take these two independent halves in the opposite order, so one
+//     wave's matrix burst sits beside its partner's vector / LDS / store work.
 // Arithmetic is the same k-ordered MFMA chain as gemm_nt_kernel, so results are bit-identical to it.
 #include "common.h"
 #include <stdlib.h>
@@ -29,8 +30,8 @@ namespace {
 constexpr int RS_RA = 4;                    // A ring depth (pairs of row blocks)
 constexpr int RS_RE = 4;                    // epilogue-operand ring depth (pairs)
 constexpr int RS_PAIR = 32 * 512;           // one pair: 32 rows x 256 16-bit elements
-constexpr int RS_TP = 144;                  // pitch (bytes) of the wave-private output image: 64 x 16-bit + 16
-constexpr int RS_TW = 16 * RS_TP;           // one wave's image: 16 rows
+constexpr int RS_TP = 80;                   // pitch (bytes) of the wave-private output image: 32 x 16-bit + 16
+constexpr int RS_TW = 32 * RS_TP;           // one wave's image: 32 rows
 constexpr int RS_LDS = (RS_RA + RS_RE) * RS_PAIR + 8 * RS_TW;   // 149,504 B
 
 struct RsGemm {
@@ -41,7 +42,6 @@ struct RsGemm {
   int nblk, groups, ns;                     // 16-row blocks, row groups, 256-column slices
   DropCfg d1, d2;
   float gate_scale;
-  int dbg;                                  // diagnostic bits (timing experiments only, results are wrong when set)
 };
 
 __device__ __forceinline__ void dma16(const char* g, char* l) {
@@ -92,9 +92,7 @@ __global__ __launch_bounds__(512, 2) void rs_gemm_kernel(RsGemm p) {
   char* const ringA = smem;
   char* const ringE = smem + RS_RA * RS_PAIR;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;                   // row block of the pair, 64-column group of the slice
-  const bool late = wm == 1;                                 // waves 4-7 run their epilogues half a step behind (SIMD partners)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // owns columns 32*wave .. +31 of the slice, all 32 rows of a pair
   const int l15 = lane & 15, g4 = lane >> 4;
   char* const timg = smem + (RS_RA + RS_RE) * RS_PAIR + wave * RS_TW;
 
@@ -139,20 +137,20 @@ __global__ __launch_bounds__(512, 2) void rs_gemm_kernel(RsGemm p) {
   }
   asm volatile("" ::: "memory");
 
-  // register-stationary weights: this wave's 64 columns as MFMA A-operands (rows of W)
-  bf16x8 wf[4][8];
+  // register-stationary weights: this wave's 32 columns as MFMA A-operands (rows of W)
+  bf16x8 wf[2][8];
   {
-    const bf16_t* wrow = p.W + (size_t)(n0 + 64 * wn + l15) * (size_t)p.ldw + 8 * g4;
+    const bf16_t* wrow = p.W + (size_t)(n0 + 32 * wave + l15) * (size_t)p.ldw + 8 * g4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int s = 0; s < 8; ++s) wf[j][s] = *(const bf16x8*)(wrow + (size_t)(16 * j) * (size_t)p.ldw + 32 * s);
   }
-  // per-lane epilogue constants: accumulator register q of tile j is column n0 + 64wn + 16j + 4*g4 + q of row l15
-  const int ncol = n0 + 64 * wn + 4 * g4;
-  float bv[4][4];
+  // per-lane epilogue constants: accumulator register q of tile j is column n0 + 32w + 16j + 4*g4 + q of row l15
+  const int ncol = n0 + 32 * wave + 4 * g4;
+  float bv[2][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < 2; ++j) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) bv[j][q] = 0.f;
     if (p.bias) load4(p.bias + ncol + 16 * j, bv[j]);
@@ -162,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void rs_gemm_kernel(RsGemm p) {
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // weights in registers, pair 0 in the ring (this wave's part)
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(wf[j][s]));
   // the rest of the rings goes in flight (A: pairs 1, 2; epilogue operand: pair 1); the tally of issued instructions starts here
@@ -176,115 +174,120 @@ __global__ __launch_bounds__(512, 2) void rs_gemm_kernel(RsGemm p) {
   int mkA2 = mark_a, mkA1 = vm_issued, mkE1 = mark_a;        // tallies right after the request of pair t+1 (A) / t+2 (A) / t+1 (E)
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // pair 0 is visible to every wave
 
-  f32x4 acc[4];
-  // epilogue of this wave's block of one pair, straight from the accumulators (wave-local)
-  auto epilogue = [&](int pair) {
-    if (2 * pair + wm >= nb) return;                         // the odd tail of the range has no second block
+  // epilogue of one pair from the accumulators `a` (wave-local: bias / ReLU / gate / dropout / residual in the MFMA layout,
+  // then through the wave's 32 x 32 LDS image so that a lane stores 16 B and an instruction covers 16 rows x 64 B)
+  auto epilogue = [&](int pair, const f32x4 (&a)[2][2]) {
     const int slotE = pair % RS_RE;
-    const int r = 16 * wm + l15;                             // row within the pair (MFMA layout)
-    const uint32_t mrow = (uint32_t)min(row0 + pair * 32 + r, p.M - 1);
-    const uint32_t drow = mrow * (uint32_t)p.N;
-    // rows this lane stores after the transposition: lane/8 and lane/8 + 8 of the block, 16 B at column 8*(lane%8)
-    const int sr = lane >> 3, sc = lane & 7;
-    const uint32_t m0 = (uint32_t)min(row0 + pair * 32 + 16 * wm + sr, p.M - 1);
-    const uint32_t m1 = (uint32_t)min(row0 + pair * 32 + 16 * wm + sr + 8, p.M - 1);
-    float v[4][4];
+    const int nvalid = min(2, nb - 2 * pair);
+    // rows this lane stores after the transposition: lane/4 of each block, 16 B at column 8*(lane%4)
+    const int sr = lane >> 2, sc = lane & 3;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = ncol + 16 * j;
+    for (int b = 0; b < 2; ++b) {
+      if (b >= nvalid) break;                                // the odd tail of the range has no second block
+      const int r = 16 * b + l15;                            // row within the pair (MFMA layout)
+      const uint32_t mrow = (uint32_t)min(row0 + pair * 32 + r, p.M - 1);
+      const uint32_t drow = mrow * (uint32_t)p.N;
+      const uint32_t ms = (uint32_t)min(row0 + pair * 32 + 16 * b + sr, p.M - 1);
+      float v[2][4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        v[j][q] = acc[j][q] + bv[j][q];
-        if (RELU) v[j][q] = fmaxf(v[j][q], 0.f);
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[j][q] = a[b][j][q] + bv[j][q];
+          if (RELU) v[j][q] = fmaxf(v[j][q], 0.f);
+        }
+        if (EMODE == 2) {
+          float ev[4];
+          const int ch = (4 * wave + 2 * j + (g4 >> 1)) ^ (r & 15);
+          load4((const bf16_t*)(ringE + slotE * RS_PAIR + r * 512 + (ch << 4) + ((g4 & 1) << 3)), ev);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[j][q] = ev[q] > 0.f ? v[j][q] * p.gate_scale : 0.f;
+        }
+        if (DROP) {
+          const uint32_t idx = drow + (uint32_t)(ncol + 16 * j);
+          eg_dropout_run<4>(v[j], p.d1, seed_lo, seed_hi, idx);
+          eg_dropout_run<4>(v[j], p.d2, seed_lo, seed_hi, idx);
+        }
       }
-      if (EMODE == 2) {
-        float ev[4];
-        const int ch = (8 * wn + 2 * j + (g4 >> 1)) ^ (r & 15);
-        load4((const bf16_t*)(ringE + slotE * RS_PAIR + r * 512 + (ch << 4) + ((g4 & 1) << 3)), ev);
+      char* const tb = timg + b * (16 * RS_TP);
+      if (p.out_pre) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[j][q] = ev[q] > 0.f ? v[j][q] * p.gate_scale : 0.f;
+        for (int j = 0; j < 2; ++j) *(u32x2*)(tb + l15 * RS_TP + (16 * j + 4 * g4) * 2) = rs_pack4(v[j]);
+        const u32x4 o = *(const u32x4*)(tb + sr * RS_TP + sc * 16);
+        *(u32x4*)(p.out_pre + (size_t)(ms * (uint32_t)p.ldp) + n0 + 32 * wave + 8 * sc) = o;
+        vm_issued += 1;
       }
-      if (DROP) {
-        const uint32_t idx = drow + (uint32_t)n;
-        eg_dropout_run<4>(v[j], p.d1, seed_lo, seed_hi, idx);
-        eg_dropout_run<4>(v[j], p.d2, seed_lo, seed_hi, idx);
-      }
-    }
-    const bool nostore = p.dbg & 1;
-    if (p.out_pre) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *(u32x2*)(timg + l15 * RS_TP + (16 * j + 4 * g4) * 2) = rs_pack4(v[j]);
-      const u32x4 o0 = *(const u32x4*)(timg + sr * RS_TP + sc * 16);
-      const u32x4 o1 = *(const u32x4*)(timg + (sr + 8) * RS_TP + sc * 16);
-      if (!nostore) {
-        *(u32x4*)(p.out_pre + (size_t)(m0 * (uint32_t)p.ldp) + n0 + 64 * wn + 8 * sc) = o0;
-        *(u32x4*)(p.out_pre + (size_t)(m1 * (uint32_t)p.ldp) + n0 + 64 * wn + 8 * sc) = o1;
-        vm_issued += 2;
-      }
-    }
+      for (int j = 0; j < 2; ++j) {
+        if (EMODE == 1) {
+          float ev[4];
+          const int ch = (4 * wave + 2 * j + (g4 >> 1)) ^ (r & 15);
+          load4((const bf16_t*)(ringE + slotE * RS_PAIR + r * 512 + (ch << 4) + ((g4 & 1) << 3)), ev);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (EMODE == 1) {
-        float ev[4];
-        const int ch = (8 * wn + 2 * j + (g4 >> 1)) ^ (r & 15);
-        load4((const bf16_t*)(ringE + slotE * RS_PAIR + r * 512 + (ch << 4) + ((g4 & 1) << 3)), ev);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[j][q] += ev[q];
+          for (int q = 0; q < 4; ++q) v[j][q] += ev[q];
+        }
+        *(u32x2*)(tb + l15 * RS_TP + (16 * j + 4 * g4) * 2) = rs_pack4(v[j]);
       }
-      *(u32x2*)(timg + l15 * RS_TP + (16 * j + 4 * g4) * 2) = rs_pack4(v[j]);
-    }
-    const u32x4 o0 = *(const u32x4*)(timg + sr * RS_TP + sc * 16);
-    const u32x4 o1 = *(const u32x4*)(timg + (sr + 8) * RS_TP + sc * 16);
-    if (!nostore) {
-      *(u32x4*)(p.C + (size_t)(m0 * (uint32_t)p.ldc) + n0 + 64 * wn + 8 * sc) = o0;
-      *(u32x4*)(p.C + (size_t)(m1 * (uint32_t)p.ldc) + n0 + 64 * wn + 8 * sc) = o1;
-      vm_issued += 2;
-    } else {
-      asm volatile("" :: "v"(o0), "v"(o1));
+      const u32x4 o = *(const u32x4*)(tb + sr * RS_TP + sc * 16);
+      *(u32x4*)(p.C + (size_t)(ms * (uint32_t)p.ldc) + n0 + 32 * wave + 8 * sc) = o;
+      vm_issued += 1;
     }
   };
-
-  int slotA = 0;
-  for (int t = 0; t < npairs; ++t) {
-    // -- keep the rings full: A pair t+3 goes into the slot pair t-1 has left, E pair t+2 into the slot pair t-2 has left --
-    if (!(p.dbg & 8)) {
-      if (t + 3 < npairs) issueA(t + 3, (t + 3) % RS_RA);
-      if (EMODE && t + 2 < npairs) issueE(t + 2, (t + 2) % RS_RE);
+  auto frags_mma = [&](int slot, f32x4 (&a)[2][2]) {
+    // fragments of the pair (swizzled rows), 32 MFMAs: D[n][m] = sum_k W[n][k] X[m][k]
+    bf16x8 xf[2][8];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const char* ab = ringA + slot * RS_PAIR + (16 * b + l15) * 512;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) xf[b][s] = *(const bf16x8*)(ab + (((4 * s + g4) ^ l15) << 4));
     }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) a[b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) a[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], xf[b][s], a[b][j], 0, 0, 0);
+  };
+
+  // Software pipeline: between two barriers a wave runs the MFMAs of pair t AND the epilogue of pair t-1 (two accumulator
+  // sets, roles swapped every step), so the matrix pipe works while the vector / LDS / store side of the previous pair drains.
+  f32x4 accP[2][2], accQ[2][2];
+  int slotA = 0;
+  auto step = [&](int t, f32x4 (&cur)[2][2], f32x4 (&prev)[2][2]) {
+    if (t + 3 < npairs) issueA(t + 3, (t + 3) % RS_RA);
+    if (EMODE && t + 2 < npairs) issueE(t + 2, (t + 2) % RS_RE);
     const int mk0 = vm_issued;
     asm volatile("" ::: "memory");
-    if (late && t > 0) epilogue(t - 1);
-    asm volatile("" ::: "memory");
-    // -- fragments of this wave's block (swizzled rows), 32 MFMAs: D[n][m] = sum_k W[n][k] X[m][k] --
-    bf16x8 xf[8];
-    {
-      const char* ab = ringA + slotA * RS_PAIR + (16 * wm + l15) * 512;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) xf[s] = *(const bf16x8*)(ab + (((4 * s + g4) ^ l15) << 4));
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!(p.dbg & 2)) {
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], xf[s], acc[j], 0, 0, 0);
+    // waves 4-7 are the SIMD partners of waves 0-3: they take the two independent halves of a step in the opposite order, so
+    // one wave's MFMA burst runs beside its partner's vector / LDS / store work instead of beside another MFMA burst
+    if (wave < 4) {
+      frags_mma(slotA, cur);
+      if (t > 0) epilogue(t - 1, prev);
     } else {
-#pragma unroll
-      for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(xf[s]));
+      if (t > 0) epilogue(t - 1, prev);
+      frags_mma(slotA, cur);
     }
     asm volatile("" ::: "memory");
-    if (!late) epilogue(t);
-    asm volatile("" ::: "memory");
-    // -- pair t+1 (and its epilogue operand) must have landed before the barrier that publishes it --
-    if (t + 1 < npairs && !(p.dbg & 4)) wait_vmcnt(vm_issued - (EMODE ? mkE1 : mkA2));
-    if (!(p.dbg & 16)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // pair t+1 (and its epilogue operand) must have landed before the barrier that publishes it
+    if (t + 1 < npairs) wait_vmcnt(vm_issued - (EMODE ? mkE1 : mkA2));
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     mkA2 = mkA1;
     mkA1 = mk0;
     mkE1 = mk0;
     slotA = slotA + 1 == RS_RA ? 0 : slotA + 1;
+  };
+  for (int t = 0; t < npairs; t += 2) {
+    step(t, accP, accQ);
+    if (t + 1 < npairs) step(t + 1, accQ, accP);
   }
-  if (late && npairs > 0) epilogue(npairs - 1);
+  if (npairs > 0) {
+    if (npairs & 1) epilogue(npairs - 1, accP); else epilogue(npairs - 1, accQ);
+  }
 }
 
 }  // namespace
@@ -325,8 +328,6 @@ int eg_rs_gemm_try(const eg_gemm_desc* d, hipStream_t s) {
   p.d1 = make_drop(d->drop1_p, d->drop1_site);
   p.d2 = make_drop(d->drop2_p, d->drop2_site);
   p.gate_scale = d->gate_scale == 0.f ? 1.0f : d->gate_scale;
-  static const int dbg = [] { const char* e = getenv("EYEGAZE_RS_DBG"); return e ? atoi(e) : 0; }();
-  p.dbg = dbg;
   const dim3 grid(p.groups * p.ns), blk(512);
 #define RS_LAUNCH(E_, R_, D_)                                                                                          \
   do {                                                                                                                 \

@@ -34,10 +34,49 @@ class HipAdamW:
     def set_epoch(self, epoch: int, t_max: int):
         """CosineAnnealingLR(T_max=t_max, eta_min=0) evaluated at `epoch` (closed form)."""
         self.lr = self.base_lr * (1 + math.cos(math.pi * epoch / t_max)) / 2
+        self.epoch, self.t_max = epoch, t_max
+
+    def scheduler_state_dict(self):
+        """The fields torch.optim.lr_scheduler.CosineAnnealingLR.state_dict() carries (train_art.py:480-491 stores them in the
+        periodic checkpoints), so `CosineAnnealingLR.load_state_dict` accepts it."""
+        ep = getattr(self, "epoch", 0)
+        return {"T_max": getattr(self, "t_max", 1), "eta_min": 0.0, "base_lrs": [self.base_lr], "last_epoch": ep,
+                "_step_count": ep + 1, "_last_lr": [self.lr]}
 
     def state_dict(self):
-        return {"t": self.t, "lr": self.lr, "base_lr": self.base_lr, "m": self.m, "v": self.v}
+        """torch.optim.AdamW's layout (`state` keyed by parameter index in named_parameters() order, one `param_groups`
+        entry), so a checkpoint written here loads into the reference's optimizer and the other way round."""
+        self._ensure()
+        fp = self.model._flat
+        state = {}
+        for i, (n, p) in enumerate(zip(fp.names, fp.params)):
+            o = fp.offsets[n]
+            state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": self.m[o:o + p.numel()].view(p.shape).clone(),
+                        "exp_avg_sq": self.v[o:o + p.numel()].view(p.shape).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": True, "initial_lr": self.base_lr, "params": list(range(len(fp.names)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.t, self.lr, self.base_lr = sd["t"], sd["lr"], sd["base_lr"]
-        self.m, self.v = sd["m"], sd["v"]
+        if "param_groups" not in sd:          # round-1 layout {t, lr, base_lr, m, v}
+            self.t, self.lr, self.base_lr = sd["t"], sd["lr"], sd["base_lr"]
+            self.m, self.v = sd["m"], sd["v"]
+            return
+        self._ensure()
+        fp = self.model._flat
+        g = sd["param_groups"][0]
+        self.lr, self.base_lr = g["lr"], g.get("initial_lr", g["lr"])
+        self.betas, self.eps, self.weight_decay = tuple(g["betas"]), g["eps"], g["weight_decay"]
+        self.m.zero_()
+        self.v.zero_()
+        steps = [0.0]
+        for i, (n, p) in enumerate(zip(fp.names, fp.params)):
+            st = sd["state"].get(i)
+            if st is None:                    # torch keeps no state for parameters that never received a gradient
+                continue
+            o = fp.offsets[n]
+            self.m[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+            self.v[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.append(float(st["step"]))
+        self.t = int(max(steps))

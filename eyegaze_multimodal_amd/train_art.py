@@ -5,8 +5,8 @@ Same command line (`python train_art.py --config <yaml>`, the form run_experimen
 YAML schema (4_Experiments/configs/dual_eeg_transformer.yaml: ablation / model / data / training / system / wandb).
 Differences, all additive:
   * the step runs natively: forward + backward + clip(1.0) + AdamW are HIP kernels over flat buffers
-    (no autograd graph); the auxiliary batch-level losses (off by default, yaml :96-101) are honoured by
-    falling back to the autograd-compatible module call for those steps;
+    (no autograd graph); the auxiliary batch-level losses (off by default, yaml :96-101) are evaluated on the [B, d]
+    outputs and their gradients w.r.t. cls1 / cls2 / ibs_token are injected into the HIP backward;
   * one process per GPU when launched under torchrun: per-rank sample sharding r::world, bucketed RCCL
     all-reduce overlapped with backward (ddp.py);
   * `data.synthetic: true` (or a missing EEG directory) trains on the class-conditional synthetic windows of
@@ -119,11 +119,15 @@ class Trainer:
         need_aux = any(self.aux.values())
         eng.forward(eeg1, eeg2, labels, train=True)
         one = torch.ones(1, device=self.device)
+        zero = torch.zeros((), device=self.device)
         kw = {}
-        losses = {"loss_ce": eng.a["loss"]}
+        # the six entries train_epoch accumulates (train_art.py:224-229), disabled terms stay 0 as there (:183-186)
+        losses = {"loss": None, "loss_ce": eng.a["loss"].reshape(()), "loss_sym": zero, "loss_ibs": zero, "loss_ibs_cls": zero,
+                  "loss_ibs_contrastive": zero}
         if self.has_ibs:
             kw["gloss_ibs"] = one * self.lam_ibs_cls
-            losses["loss_ibs_cls"] = eng.a["ibs_loss"]
+            if self.lam_ibs_cls != 0.0:
+                losses["loss_ibs_cls"] = eng.a["ibs_loss"].reshape(())
         if need_aux:
             # batch-level losses on [B,d] outputs: evaluated with torch ops, their gradients enter the HIP backward
             cls1 = eng.a["cls1"].clone().requires_grad_(True)
@@ -146,6 +150,8 @@ class Trainer:
         if self.reducer:
             self.reducer.finish()
         self.opt.step(eng)
+        losses["loss"] = (losses["loss_ce"] + self.lams["sym"] * losses["loss_sym"] + self.lams["ibs"] * losses["loss_ibs"] +
+                          self.lam_ibs_cls * losses["loss_ibs_cls"] + self.lams["contrastive"] * losses["loss_ibs_contrastive"])
         return {k: v.detach() for k, v in losses.items()}
 
     @torch.no_grad()
@@ -159,16 +165,16 @@ class Trainer:
             n += 1
             preds.append(torch.argmax(out["logits"], dim=-1).cpu().numpy())
             labs.append(labels.cpu().numpy())
-        yp, yt = np.concatenate(preds), np.concatenate(labs)
+        empty = np.zeros(0, dtype=np.int64)
+        yp, yt = np.concatenate(preds or [empty]), np.concatenate(labs or [empty])   # a rank's shard may hold no batch
         if self.world > 1:
             gathered = [None] * self.world
             dist.all_gather_object(gathered, (yp, yt, tot, n))
             yp = np.concatenate([g[0] for g in gathered])
             yt = np.concatenate([g[1] for g in gathered])
             tot, n = sum(g[2] for g in gathered), sum(g[3] for g in gathered)
-        m = macro_metrics(yt, yp)
-        m["eval/loss"] = tot / max(n, 1)
-        return m
+        m = macro_metrics(yt, yp) if len(yt) else {"eval/accuracy": 0.0, "eval/precision": 0.0, "eval/recall": 0.0, "eval/f1": 0.0}
+        return {"eval/loss": tot / max(n, 1), **m}
 
 
 def split_items(items, test_size: float, seed: int):
@@ -186,12 +192,40 @@ def split_items(items, test_size: float, seed: int):
         return [items[i] for i in perm[n_test:]], [items[i] for i in perm[:n_test]]
 
 
-def prepare_shards(config: Dict[str, Any], out_dir: Path, rank: int = 0, world: int = 1) -> Dict[str, Path]:
-    """CSV recordings -> windowed shards, once (rank 0 builds; the others wait on the barrier)."""
+def shard_fingerprint(config: Dict[str, Any]) -> str:
+    """Hash of everything the cached windows depend on: a re-run with other data settings must not train on stale shards."""
+    import hashlib
     import json
     d = config["data"]
+    meta = Path(d["metadata_path"])
+    stt = meta.stat() if meta.exists() else None
+    key = {k: d.get(k) for k in ("window_size", "stride", "max_samples", "train_test_split", "random_seed", "label2id",
+                                 "eeg_base_path", "metadata_path")}
+    key["metadata_stat"] = [stt.st_size, int(stt.st_mtime)] if stt else None
+    return hashlib.sha256(json.dumps(key, sort_keys=True, default=str).encode()).hexdigest()[:16]
+
+
+def prepare_shards(config: Dict[str, Any], out_dir: Path, rank: int = 0, world: int = 1, timeout_s: float = 24 * 3600.0) -> Dict[str, Path]:
+    """CSV recordings -> windowed shards, once per data configuration.  Rank 0 builds and then writes `<out_dir>/READY`
+    holding the fingerprint; the other ranks poll that file (no collective: a long CSV conversion must not run into the
+    process group's timeout).  Shards built under another fingerprint are rebuilt."""
+    import json
+    import shutil
+    import time
+    d = config["data"]
     dirs = {"train": out_dir / "train", "test": out_dir / "test"}
-    if rank == 0 and not all((p / "index.json").exists() for p in dirs.values()):
+    fp = shard_fingerprint(config)
+    ready = out_dir / "READY"
+
+    def is_ready():
+        return ready.exists() and ready.read_text().strip() == fp and all((p / "index.json").exists() for p in dirs.values())
+
+    if rank == 0 and not is_ready():
+        if ready.exists():
+            ready.unlink()
+        for p in dirs.values():
+            if p.exists():
+                shutil.rmtree(p)              # stale windows of another configuration
         items = json.loads(Path(d["metadata_path"]).read_text())
         if d.get("max_samples"):
             items = items[: d["max_samples"]]
@@ -199,15 +233,36 @@ def prepare_shards(config: Dict[str, Any], out_dir: Path, rank: int = 0, world: 
         for name, its in (("train", train_items), ("test", test_items)):
             idx = build_window_shards(its, d["eeg_base_path"], d["label2id"], dirs[name], d["window_size"], d["stride"])
             logger.info(f"{name}: {len(its)} recordings -> {idx['count']} windows in {len(idx['shards'])} shards")
-    if world > 1:
-        dist.barrier()
+        out_dir.mkdir(parents=True, exist_ok=True)
+        ready.write_text(fp)
+    t0 = time.time()
+    while not is_ready():
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError(f"rank {rank}: window shards under {out_dir} did not become ready")
+        time.sleep(0.5)
     return dirs
 
 
 def _batches(x1, x2, y, bs, device, idx):
-    for i in range(0, len(idx) - bs + 1, bs):
+    """every sample, the tail batch included (the reference's test DataLoader keeps it, train_art.py:343-350)"""
+    for i in range(0, len(idx), bs):
         j = idx[i:i + bs]
         yield x1[j].to(device), x2[j].to(device), y[j].to(device)
+
+
+TRAIN_KEYS = ("loss", "loss_ce", "loss_sym", "loss_ibs", "loss_ibs_cls", "loss_ibs_contrastive")
+
+
+def checkpoint_dict(tr: "Trainer", epoch: int, config, *, best_f1=None, metrics=None, periodic: bool = False) -> Dict[str, Any]:
+    """Key sets of the reference's two torch.save calls (train_art.py:469-475 best model, :482-489 periodic checkpoint)."""
+    ck = {"epoch": epoch, "model_state_dict": tr.model.state_dict(), "optimizer_state_dict": tr.opt.state_dict()}
+    if periodic:
+        ck["scheduler_state_dict"] = tr.opt.scheduler_state_dict()
+        ck["metrics"] = metrics
+    else:
+        ck["best_f1"] = best_f1
+    ck["config"] = config
+    return ck
 
 
 def main(args):
@@ -229,7 +284,7 @@ def main(args):
     use_csv = not d.get("synthetic", False) and eeg_dir.exists() and any(eeg_dir.glob("*.csv"))
     shards = None
     if use_csv:
-        shards = prepare_shards(config, Path(t["output_dir"]) / "window_shards", rank, world)
+        shards = prepare_shards(config, Path(t["output_dir"]) / "window_shards", rank, world)   # file-based wait, no collective
     else:
         n_total = d.get("max_samples") or d.get("synthetic_samples", 2048)
         logger.info(f"synthetic class-conditional windows: n={n_total} C={C} T={T} classes={ncls}")
@@ -256,21 +311,24 @@ def main(args):
         tr.opt.set_epoch(epoch, tr.epochs)           # CosineAnnealingLR stepped per epoch (train_art.py:409,494)
         sums, nb = {}, 0
         if shards is not None:
+            # one process: every window, tail batch included, as the reference's DataLoader (train_art.py:334-341);
+            # data parallel: every rank must take the same number of steps, so the ragged tail is dropped
             train_ld = WindowShards(shards["train"], bs, device, rank, world, shuffle=True, seed=d["random_seed"],
-                                    preprocessing=d.get("enable_preprocessing", False), drop_last=True)
+                                    preprocessing=d.get("enable_preprocessing", False), drop_last=world > 1)
             train_ld.set_epoch(epoch)
             train_iter = ((b["eeg1"], b["eeg2"], b["labels"]) for b in train_ld)
         else:
             order = np.random.default_rng(d["random_seed"] + epoch).permutation(train_idx)
             gbs = bs * world
+            stop = len(order) if world == 1 else len(order) - gbs + 1
             train_iter = ((x1[m].to(device), x2[m].to(device), y[m].to(device)) for m in
-                          (order[i:i + gbs][list(shard_indices(gbs, rank, world))] for i in range(0, len(order) - gbs + 1, gbs)))
+                          (order[i:i + gbs][list(shard_indices(len(order[i:i + gbs]), rank, world))] for i in range(0, stop, gbs)))
         for e1, e2, lab in train_iter:
             losses = tr.train_step(e1, e2, lab)
             for k, v in losses.items():
                 sums[k] = sums.get(k, 0.0) + v.float()
             nb += 1
-        train_metrics = {f"train/{k}": float(v) / max(nb, 1) for k, v in sums.items()}
+        train_metrics = {f"train/{k}": float(sums.get(k, 0.0)) / max(nb, 1) for k in TRAIN_KEYS}   # train_art.py:248-255
         if shards is not None:
             test_ld = WindowShards(shards["test"], ebs, device, rank, world, preprocessing=d.get("enable_preprocessing", False))
             ev = tr.evaluate((b["eeg1"], b["eeg2"], b["labels"]) for b in test_ld)
@@ -284,17 +342,35 @@ def main(args):
                 wandb.log(metrics)
             if ev["eval/f1"] > best_f1:
                 best_f1, best_epoch = ev["eval/f1"], epoch + 1
-                torch.save({"epoch": epoch + 1, "model_state_dict": tr.model.state_dict(),
-                            "optimizer_state_dict": tr.opt.state_dict(), "best_f1": best_f1, "config": config},
-                           out_dir / "best_model.pt")
+                torch.save(checkpoint_dict(tr, epoch + 1, config, best_f1=best_f1), out_dir / "best_model.pt")
             if (epoch + 1) % t["save_every_n_epochs"] == 0:
-                torch.save({"epoch": epoch + 1, "model_state_dict": tr.model.state_dict(),
-                            "optimizer_state_dict": tr.opt.state_dict(), "metrics": metrics, "config": config},
+                torch.save(checkpoint_dict(tr, epoch + 1, config, metrics=metrics, periodic=True),
                            out_dir / f"checkpoint-epoch-{epoch + 1}.pt")
     if rank == 0:
         logger.info(f"Training completed! Best F1: {best_f1:.4f} at epoch {best_epoch}")
+    # final evaluation on the best model (train_art.py:503-512); every rank loads it so that the sharded evaluate() agrees
+    final = None
+    best_path = out_dir / "best_model.pt"
+    if world > 1:
+        dist.barrier()
+    if best_path.exists():
+        ck = torch.load(best_path, map_location="cpu", weights_only=False)   # our own file, written above
+        tr.model.load_state_dict(ck["model_state_dict"])
+        if shards is not None:
+            test_ld = WindowShards(shards["test"], ebs, device, rank, world, preprocessing=d.get("enable_preprocessing", False))
+            final = tr.evaluate((b["eeg1"], b["eeg2"], b["labels"]) for b in test_ld)
+        else:
+            my_test = test_idx[list(shard_indices(len(test_idx), rank, world))]
+            final = tr.evaluate(_batches(x1, x2, y, min(ebs, max(1, len(my_test))), device, my_test))
+        if rank == 0:
+            logger.info("Final Test Metrics: " + " ".join(f"{k}: {v:.4f}" for k, v in final.items()))
+            if wandb:
+                wandb.log({f"final/{k}": v for k, v in final.items()})
+    if wandb:
+        wandb.finish()
     if world > 1:
         dist.destroy_process_group()
+    return final
 
 
 if __name__ == "__main__":

@@ -48,18 +48,22 @@ def bench(M, N, K, residual=0, gate=0, act=0, drop=0.0, ln=0, reps=40):
 
 
 M = 33280
-if os.environ.get("RS_SHORT"):
+if os.environ.get("RS_SHORT") == "skip":
+    pass
+elif os.environ.get("RS_SHORT"):
     bench(M, 768, 256)
     bench(M, 1024, 256, act=1, drop=0.1)
     bench(M, 256, 256, residual=1)
     bench(4 * M, 256, 256, residual=1)
     sys.exit(0)
-bench(M, 768, 256)
-bench(M, 256, 256, residual=1, drop=0.1)
-bench(M, 256, 256, residual=1, drop=0.1, ln=1)
-bench(M, 1024, 256, act=1, drop=0.1)
-bench(M, 1024, 256, gate=1)
-bench(M, 256, 256)
-bench(M, 256, 256, residual=1)
-bench(4 * M, 256, 256, residual=1)
-bench(4 * M, 1024, 256, act=1, drop=0.1)
+if os.environ.get("RS_SHORT") == "skip":
+    M = 0
+if M: bench(M, 768, 256)
+if M: bench(M, 256, 256, residual=1, drop=0.1)
+if M: bench(M, 256, 256, residual=1, drop=0.1, ln=1)
+if M: bench(M, 1024, 256, act=1, drop=0.1)
+if M: bench(M, 1024, 256, gate=1)
+if M: bench(M, 256, 256)
+if M: bench(M, 256, 256, residual=1)
+if M: bench(4 * M, 256, 256, residual=1)
+if M: bench(4 * M, 1024, 256, act=1, drop=0.1)
