@@ -35,6 +35,9 @@ WORKLOADS = {
              "BASELINE configs[4]: + STFT image -> 2-D CNN tokens per channel (third modality), cross-attention fusion"),
     "a5": (dict(use_spectrogram=True, use_ibs=True, use_robust_ibs=True, use_cross_attention=True),
            "reference default flags (A5): spectrogram tokens + 42 inter-stream synchrony tokens + cross-attention, loss_ce + loss_ibs_cls"),
+    "a5c32": (dict(use_spectrogram=True, use_ibs=True, use_robust_ibs=True, use_cross_attention=True, in_channels=32),
+              "the reference's default yaml (4_Experiments/configs/dual_eeg_transformer.yaml:38-53): A5 flags at in_channels = 32 "
+              "(S = 139, 1024-wide synchrony rows)"),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
@@ -171,9 +174,10 @@ def main():
     from eyegaze_multimodal_amd.data import randn_windows
     from eyegaze_multimodal_amd.ddp import GradAllReducer, broadcast_params, bucket_ranges
 
-    C, T, B = 8, 1024, args.batch
+    T, B = 1024, args.batch
     kw, desc = WORKLOADS[args.workload]
     kw = dict(kw, num_classes=3)
+    C = kw.pop("in_channels", 8)
     torch.manual_seed(42)
     model = DualEEGTransformer(in_channels=C, max_len=T // 4, compute_dtype=args.dtype, **kw).to(dev)
     model.train()

@@ -5,3 +5,4 @@ from .dual_eeg_transformer import DualEEGTransformer  # noqa: F401
 from .optim import HipAdamW  # noqa: F401
 
 __all__ = ["DualEEGTransformer", "HipAdamW", "EgError", "EG_BF16", "EG_F32", "LIB_PATH"]
+from . import ops  # noqa: E402,F401  (registers the eyegaze::* operators with torch.library)

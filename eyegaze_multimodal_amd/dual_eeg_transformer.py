@@ -158,35 +158,6 @@ def _resolve_dtype(compute_dtype: Optional[str]) -> int:
     raise ValueError(f"compute_dtype must be 'bf16' or 'f32', got {name!r}")
 
 
-class _HipFn(torch.autograd.Function):
-    """One autograd node for the whole module: forward and backward are the HIP engine's."""
-
-    @staticmethod
-    def forward(ctx, model, eng, eeg1, eeg2, labels, *params):
-        outs = model._run_forward(eng, eeg1, eeg2, labels)
-        ctx.model, ctx.eng, ctx.keys, ctx.fwd_id = model, eng, list(outs.keys()), model._fwd_count
-        return tuple(outs.values())
-
-    @staticmethod
-    def backward(ctx, *gouts):
-        model, eng = ctx.model, ctx.eng
-        if model._fwd_count != ctx.fwd_id:
-            raise L.EgError("backward() called after a newer forward(): the engine keeps one step's activations")
-        g = {k: (v.contiguous().float() if v is not None else None) for k, v in zip(ctx.keys, gouts)}
-        one = lambda t: None if t is None else t.reshape(1)
-        eng.backward(gloss=one(g.get("loss_ce")), gloss_ibs=one(g.get("loss_ibs_cls")), glogits=g.get("logits"),
-                     gcls1=g.get("cls1"), gcls2=g.get("cls2"), gibs_logits=g.get("ibs_logits"), gibs_token=g.get("ibs_token"))
-        from . import tokens
-        tokens.fire_spec_backward_hooks(model, eng)
-        fp = model._flat
-        flat = fp.grad.clone()
-        grads = []
-        for n, p in zip(fp.names, fp.params):
-            o = fp.offsets[n]
-            grads.append(flat[o:o + p.numel()].view(p.shape) if p.requires_grad else None)
-        return (None, None, None, None, None, *grads)
-
-
 class _AuxLoss(torch.autograd.Function):
     """loss, d loss / d tokens from one of the eg_aux_* kernels; backward = upstream scalar x the stored gradients."""
 
@@ -269,6 +240,8 @@ class DualEEGTransformer(nn.Module):
         self._engines: Dict[tuple, Engine] = {}
         self._fwd_count = 0
         self._seed_base = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+        from . import ops
+        self._op_handle = ops.register_owner(self)     # the registered operators (ops.py) find this module by handle
 
     # ------------------------------------------------------------------------------------------
     def engine(self, B: int, T: int, device: torch.device) -> Engine:
@@ -284,11 +257,12 @@ class DualEEGTransformer(nn.Module):
             self._engines[key] = eng
         return eng
 
-    def _run_forward(self, eng: Engine, eeg1, eeg2, labels) -> Dict[str, torch.Tensor]:
+    def _run_forward(self, eng: Engine, eeg1, eeg2, labels, train: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+        train = self.training if train is None else train
         self._fwd_count += 1
-        if self.training:
+        if train:
             eng.set_state(seed=self._seed_base * 1000003 + self._fwd_count, lr=0.0, step=1)
-        eng.forward(eeg1, eeg2, labels, train=self.training)
+        eng.forward(eeg1, eeg2, labels, train=train)
         a = eng.a
         out = {"logits": a["logits"].clone(), "cls1": a["cls1"].clone(), "cls2": a["cls2"].clone()}
         if self.cfg.use_ibs:
@@ -299,6 +273,23 @@ class DualEEGTransformer(nn.Module):
             if self.cfg.use_ibs:
                 out["loss_ibs_cls"] = a["ibs_loss"].clone().reshape(())
         return out
+
+    def _run_backward(self, shape, fwd_id: int, gouts: Dict[str, Optional[torch.Tensor]]):
+        """autograd formula of eyegaze::dual_eeg_forward: the HIP backward over the engine's saved activations; returns one
+        gradient per parameter (views of a copy of the flat gradient buffer, named_parameters() order)."""
+        B, T, device = shape
+        eng = self.engine(B, T, device)
+        if self._fwd_count != fwd_id:
+            raise L.EgError("backward() called after a newer forward(): the engine keeps one step's activations")
+        g = {k: (v.contiguous().float() if (v is not None and v.numel() > 0) else None) for k, v in gouts.items()}
+        one = lambda t: None if t is None else t.reshape(1)
+        eng.backward(gloss=one(g.get("loss_ce")), gloss_ibs=one(g.get("loss_ibs_cls")), glogits=g.get("logits"),
+                     gcls1=g.get("cls1"), gcls2=g.get("cls2"), gibs_logits=g.get("ibs_logits"), gibs_token=g.get("ibs_token"))
+        from . import tokens
+        tokens.fire_spec_backward_hooks(self, eng)
+        fp = self._flat
+        flat = fp.grad.clone()
+        return [flat[fp.offsets[n]:fp.offsets[n] + p.numel()].view(p.shape) for n, p in zip(fp.names, fp.params)]
 
     def forward(self, eeg1: torch.Tensor, eeg2: torch.Tensor, labels: Optional[torch.Tensor] = None) -> dict:
         """eeg1, eeg2: f32 [B, C, T] on a HIP device; labels: i64 [B] or None.  Returns the reference's dict
@@ -312,17 +303,14 @@ class DualEEGTransformer(nn.Module):
             labels = labels.to(device=eeg1.device, dtype=torch.int64).contiguous()
         eeg1, eeg2 = eeg1.contiguous().float(), eeg2.contiguous().float()
         eng = self.engine(eeg1.shape[0], eeg1.shape[2], eeg1.device)
-        # autograd node when anything upstream or inside wants gradients; analysis code (Grad-CAM) freezes the parameters and
-        # marks the INPUTS instead: the HIP path has no gradient w.r.t. the raw windows (the reference never trains through
-        # them either), their .grad stays None, but the backward still runs and feeds the hooks
-        if torch.is_grad_enabled() and (any(p.requires_grad for p in self._flat.params) or eeg1.requires_grad or eeg2.requires_grad):
-            vals = _HipFn.apply(self, eng, eeg1, eeg2, labels, *self._flat.params)
-            keys = ["logits", "cls1", "cls2"] + (["ibs_logits", "ibs_token"] if self.cfg.use_ibs else [])
-            if labels is not None:
-                keys += ["loss_ce"] + (["loss_ibs_cls"] if self.cfg.use_ibs else [])
-            out = dict(zip(keys, vals))
-        else:
-            out = self._run_forward(eng, eeg1, eeg2, labels)
+        # The whole forward is ONE registered operator, eyegaze::dual_eeg_forward (ops.py); its autograd formula is the HIP
+        # backward.  Analysis code (Grad-CAM) freezes the parameters and marks the INPUTS instead: the HIP path has no gradient
+        # w.r.t. the raw windows (the reference never trains through them either), their .grad stays None, but the backward
+        # still runs and feeds the hooks.
+        self.engine(eeg1.shape[0], eeg1.shape[2], eeg1.device)       # (re)flattens the parameters before they are handed over
+        from . import ops
+        vals = torch.ops.eyegaze.dual_eeg_forward(eeg1, eeg2, labels, list(self._flat.params), self._op_handle, self.training)
+        out = {k: v for k, v in zip(ops.OUTPUT_KEYS, vals) if v.numel() > 0}
         if labels is not None:
             out["loss"] = out["loss_ce"]
         return out

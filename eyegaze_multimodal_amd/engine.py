@@ -460,48 +460,65 @@ class Engine:
             return None
         g["lnpart_all"] = self._t(len(ln_names) * self.ln_nblk_cap * 2 * d, dtype=torch.float32)
         self._ln_slot = {n: i for i, n in enumerate(ln_names)}
-        tp = (L.TNProblem * len(probs))()
-        rt = (L.ReduceEntry * (len(probs) + len(ln_names)))()
-        blk, rblk, off = 0, 0, 0
-        for e, r, (names, dyn, xn, N, K, ldy) in zip(tp, rt, probs):
-            slab = N * K + N
-            base = ptr(g["wg_partial"]) + 4 * off
-            e.dY, e.X, e.partial = ptr(g[dyn]), ptr(self.a[xn]), base
-            e.ldy, e.ldx, e.N, e.K, e.part_rows, e.has_bias, e.blk0 = ldy, K, N, K, N // len(names), 1, blk
-            blk += ((N + 127) // 128) * ((K + 127) // 128) * splits
-            r.partial, r.out, r.n, r.stride, r.splits, r.blk0 = base, fp.g_ptr(names[0] + ".weight"), slab, slab, splits, rblk
-            rblk += _reduce_blocks(slab, splits)
-            off += splits * slab
-        for i, n in enumerate(ln_names):   # deferred LayerNorm gain / bias partials ride in the same reduce launch
-            r = rt[len(probs) + i]
-            r.partial, r.out = ptr(g["lnpart_all"]) + 4 * i * self.ln_nblk_cap * 2 * d, fp.g_ptr(n + ".weight")
-            # LayerNorms whose backward runs in a GEMM epilogue leave one partial per 64-row workgroup; the top layer's ln2
-            # keeps the stand-alone kernel (its input gradient comes from encoder.norm, not from a product)
-            fused = self.fuse_ln and not n.endswith(f"layers.{cfg.num_layers - 1}.ln2")
-            r.n, r.stride, r.splits, r.blk0 = 2 * d, 2 * d, ((M + 63) // 64 if fused else self.LN_BLOCKS), rblk
-            rblk += _reduce_blocks(2 * d, r.splits)
+        ln_of = {}
+        for i, n in enumerate(ln_names):
+            ln_of.setdefault(int(n.split(".")[2]), []).append((i, n))
         dev = lambda arr: torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-        # the same problems as per-layer tables (block ranges relative to the layer's own launch): used when the weight
-        # gradients of a layer are launched on the side stream as soon as that layer's backward-data chain has produced them
+        offs, off = [], 0
+        for names, dyn, xn, N, K, ldy in probs:
+            offs.append(off)
+            off += splits * (N * K + N)
+
+        def tables(layers):
+            """TN problem table + reduce table (weights, biases and the deferred LayerNorm gain / bias partials) of `layers`;
+            block ranges are relative to the tables' own launches.  Which launch a product rides in changes neither its split
+            nor its summation order, so every piece arrangement yields bit-identical gradients."""
+            sel = [4 * l + j for l in layers for j in range(4)]
+            lns = [e for l in layers for e in ln_of[l]]
+            tp = (L.TNProblem * len(sel))()
+            rt = (L.ReduceEntry * (len(sel) + len(lns)))()
+            blk, rblk = 0, 0
+            for e, r, pi in zip(tp, rt, sel):
+                names, dyn, xn, N, K, ldy = probs[pi]
+                slab = N * K + N
+                base = ptr(g["wg_partial"]) + 4 * offs[pi]
+                e.dY, e.X, e.partial = ptr(g[dyn]), ptr(self.a[xn]), base
+                e.ldy, e.ldx, e.N, e.K, e.part_rows, e.has_bias, e.blk0 = ldy, K, N, K, N // len(names), 1, blk
+                blk += ((N + 127) // 128) * ((K + 127) // 128) * splits
+                r.partial, r.out, r.n, r.stride, r.splits, r.blk0 = base, fp.g_ptr(names[0] + ".weight"), slab, slab, splits, rblk
+                rblk += _reduce_blocks(slab, splits)
+            for k, (i, n) in enumerate(lns):   # deferred LayerNorm gain / bias partials ride in the same reduce launch
+                r = rt[len(sel) + k]
+                r.partial, r.out = ptr(g["lnpart_all"]) + 4 * i * self.ln_nblk_cap * 2 * d, fp.g_ptr(n + ".weight")
+                # LayerNorms whose backward runs in a GEMM epilogue leave one partial per 64-row workgroup; the top layer's ln2
+                # keeps the stand-alone kernel (its input gradient comes from encoder.norm, not from a product)
+                fused = self.fuse_ln and not n.endswith(f"layers.{cfg.num_layers - 1}.ln2")
+                r.n, r.stride, r.splits, r.blk0 = 2 * d, 2 * d, ((M + 63) // 64 if fused else self.LN_BLOCKS), rblk
+                rblk += _reduce_blocks(2 * d, r.splits)
+            return dict(tp=dev(tp), rt=dev(rt), n=len(sel), nr=len(sel) + len(lns), blocks=blk, rblocks=rblk, layers=list(layers))
+
+        Lr = cfg.num_layers
+        whole = tables(range(Lr))
+        # the same problems as per-layer tables: used when the weight gradients of a layer are launched on the side stream as
+        # soon as that layer's backward-data chain has produced them (EYEGAZE_WGRAD_OVERLAP=1)
         per_layer = []
-        for l in range(cfg.num_layers):
-            sub = (L.TNProblem * 4)()
-            b0 = tp[4 * l].blk0
-            for j in range(4):
-                C.memmove(C.addressof(sub[j]), C.addressof(tp[4 * l + j]), C.sizeof(L.TNProblem))
-                sub[j].blk0 = tp[4 * l + j].blk0 - b0
-            nblk = (tp[4 * l + 4].blk0 if l + 1 < cfg.num_layers else blk) - b0
-            per_layer.append((dev(sub), nblk))
-        self._wg_plan = dict(tp=dev(tp), rt=dev(rt), n=len(probs), nr=len(probs) + len(ln_names), blocks=blk, rblocks=rblk,
-                             splits=splits, per_layer=per_layer)
+        for l in range(Lr):
+            t1 = tables([l])
+            per_layer.append((t1["tp"], t1["blocks"]))
+        # data parallel: two pieces, so the gradient buckets of layers L-1 .. L/2 start their all-reduce while layers L/2-1 .. 0
+        # are still in backward (one piece would hold every encoder bucket back until backward has finished)
+        h = Lr // 2
+        pieces = [tables(range(h, Lr)), tables(range(0, h))] if Lr >= 2 else [whole]
+        self._wg_plan = dict(whole, splits=splits, per_layer=per_layer, pieces=pieces, split_layer=h)
         return self._wg_plan
 
-    def _wgrad_group_launch(self):
-        pl = self._wg_plan
+    def _wgrad_group_launch(self, piece=None):
+        """piece: None = every encoder layer in one launch; else one of `_wg_plan['pieces']` (data-parallel runs)."""
+        pl = self._wg_plan if piece is None else piece
         if self._wg_side is not None:          # the per-layer launches are already queued on the side stream: join it
             torch.cuda.current_stream(self.device).wait_stream(self._wg_side)
         else:
-            call("eg_gemm_tn_grouped", ptr(pl["tp"]), pl["n"], pl["blocks"], self.M, pl["splits"], self.dtype, self.stream)
+            call("eg_gemm_tn_grouped", ptr(pl["tp"]), pl["n"], pl["blocks"], self.M, self._wg_plan["splits"], self.dtype, self.stream)
         call("eg_reduce_table", ptr(pl["rt"]), pl["nr"], pl["rblocks"], self.stream)
 
     def _wgrad_layer_async(self, l: int):
@@ -765,6 +782,10 @@ class Engine:
         if overlap and getattr(self, "_wg_side_stream", None) is None:
             self._wg_side_stream = torch.cuda.Stream(self.device)
         self._wg_side = self._wg_side_stream if overlap else None
+        # with a gradient reducer listening (data parallel) the grouped launch is cut in two pieces (see _wgrad_group_plan);
+        # EYEGAZE_WGRAD_PIECES=1 forces the cut without a reducer (bit-identity tests), =0 forbids it
+        pcs = os.environ.get("EYEGAZE_WGRAD_PIECES", "")
+        pieced = grouped and not overlap and len(self._wg_plan["pieces"]) == 2 and pcs != "0" and (on_segment is not None or pcs == "1")
 
         def attn_block_bwd(pre, l, x_in, dr, drm, kv_shift, site_attn, dx_out, dqkv, defer, ln_next=None):
             """dr: grad of the pre-LN sum (residual path), drm: same, masked by the branch dropout.
@@ -843,10 +864,21 @@ class Engine:
             dz, other = other, dz
             if not grouped:
                 seg(f"layer{l}")
+            elif pieced and l == self._wg_plan["split_layer"]:
+                # upper half of the encoder: its weight gradients are complete -> reduce them now, hand the buckets to the
+                # all-reduce while the lower layers' backward-data chain keeps the compute stream busy
+                self._wgrad_group_launch(self._wg_plan["pieces"][0])
+                for ll in reversed(self._wg_plan["pieces"][0]["layers"]):
+                    seg(f"layer{ll}")
         if grouped:
-            self._wgrad_group_launch()
-            for l in reversed(range(Lr)):
-                seg(f"layer{l}")
+            if pieced:
+                self._wgrad_group_launch(self._wg_plan["pieces"][1])
+                for ll in reversed(self._wg_plan["pieces"][1]["layers"]):
+                    seg(f"layer{ll}")
+            else:
+                self._wgrad_group_launch()
+                for l in reversed(range(Lr)):
+                    seg(f"layer{l}")
         dseq = dz
         # positional table / cls token (A:120-126, D:1157)
         call("eg_batch_rowsum", ptr(dseq), fp.g_ptr("pos_embed.pos_embed.weight"), NB, S, d, S, self.dtype, st)

@@ -15,6 +15,9 @@ class HipAdamW:
         self.t = 0
         self.m = None
         self.v = None
+        self._eng = None
+        from . import ops
+        self._op_handle = ops.register_owner(self)
 
     def _ensure(self):
         fp = self.model._flat
@@ -28,8 +31,17 @@ class HipAdamW:
         eng.set_state(seed=seed, lr=self.lr, step=self.t, grad_scale=grad_scale, beta1=self.betas[0], beta2=self.betas[1])
 
     def step(self, eng):
+        """clip_grad_norm_(max_grad_norm) + AdamW through the registered operator eyegaze::clip_adamw_step (ops.py)."""
         self._ensure()
-        eng.optimizer_step(self.m, self.v, self.max_grad_norm, self.betas, self.eps, self.weight_decay)
+        self._eng = eng
+        fp = self.model._flat
+        torch.ops.eyegaze.clip_adamw_step(fp.flat, fp.grad, self.m, self.v, self._op_handle)
+
+    def _native_step(self, flat_params, flat_grads, exp_avg, exp_avg_sq):
+        fp = self.model._flat
+        if flat_params.data_ptr() != fp.flat.data_ptr() or flat_grads.data_ptr() != fp.grad.data_ptr():
+            raise RuntimeError("eyegaze::clip_adamw_step works on the module's own flat parameter / gradient buffers")
+        self._eng.optimizer_step(exp_avg, exp_avg_sq, self.max_grad_norm, self.betas, self.eps, self.weight_decay)
 
     def set_epoch(self, epoch: int, t_max: int):
         """CosineAnnealingLR(T_max=t_max, eta_min=0) evaluated at `epoch` (closed form)."""

@@ -117,9 +117,22 @@ class Trainer:
         self.opt.begin_step(eng, seed=self.config["system"]["seed"] * 7919 + self.step_no * self.world + self.rank, grad_scale=gs)
         hook = self.reducer.on_segment if self.reducer else None
         need_aux = any(self.aux.values())
+        zero = torch.zeros((), device=self.device)
+        if not need_aux:
+            # the whole forward + backward is ONE registered operator (ops.py: eyegaze::dual_eeg_train_step)
+            self.model._on_segment = hook
+            fp = self.model._flat
+            loss_ce, loss_ibs = torch.ops.eyegaze.dual_eeg_train_step(eeg1, eeg2, labels, fp.flat, fp.grad,
+                                                                     float(self.lam_ibs_cls if self.has_ibs else 0.0),
+                                                                     self.model._op_handle)
+            if self.reducer:
+                self.reducer.finish()
+            self.opt.step(eng)
+            li = loss_ibs if (self.has_ibs and self.lam_ibs_cls != 0.0) else zero
+            return {"loss": (loss_ce + self.lam_ibs_cls * li).detach(), "loss_ce": loss_ce, "loss_sym": zero, "loss_ibs": zero,
+                    "loss_ibs_cls": li, "loss_ibs_contrastive": zero}
         eng.forward(eeg1, eeg2, labels, train=True)
         one = torch.ones(1, device=self.device)
-        zero = torch.zeros((), device=self.device)
         kw = {}
         # the six entries train_epoch accumulates (train_art.py:224-229), disabled terms stay 0 as there (:183-186)
         losses = {"loss": None, "loss_ce": eng.a["loss"].reshape(()), "loss_sym": zero, "loss_ibs": zero, "loss_ibs_cls": zero,

@@ -10,7 +10,7 @@ from oracle.dual_eeg_oracle import ModelCfg, synthetic_state_dict
 GOLDEN = Path(__file__).resolve().parent / "golden"
 WEIGHT_SEED = 20260128
 FULL_CONFIGS = ["cfg1_a1_2class", "cfg2_concat", "cfg3_xattn", "cfg5_a2_spec", "a3_ibs_scalar", "a5_full",
-                "b1_no_inorm", "b2_phase", "b3_amplitude"]
+                "b1_no_inorm", "b2_phase", "b3_amplitude", "a5_c32"]   # a5_c32: the reference's default in_channels = 32 (S = 139)
 TINY_CONFIGS = ["tiny_full", "tiny_a1"]
 ALL_CONFIGS = FULL_CONFIGS + TINY_CONFIGS
 

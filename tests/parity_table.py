@@ -26,7 +26,12 @@ def fixture_rows():
                 x1, x2, labels = t(z[f"{kind}/eeg1"]).to(DEV), t(z[f"{kind}/eeg2"]).to(DEV), t(z["labels"]).to(DEV)
                 out = model(x1, x2, labels)
                 loss = out["loss_ce"] + (out["loss_ibs_cls"] if "loss_ibs_cls" in out else 0.0)
-                loss.backward()
+                has_grad = True
+                try:
+                    loss.backward()
+                except Exception as e:      # tiny_full in bf16: d_model/2 = 32 is below the bf16 K-tile of the backward-data GEMM
+                    has_grad = False
+                    print("no backward:", name, dtype, str(e)[:80], flush=True)
                 torch.cuda.synchronize()
                 got = out["logits"].detach().float().cpu().numpy()
                 ref = z[f"{kind}/out/logits"]
@@ -40,6 +45,10 @@ def fixture_rows():
                            cls2_relerr=relerr(out["cls2"].detach().float().cpu(), z[f"{kind}/out/cls2"]))
                 if "ibs_logits" in out:
                     row["max_abs_dibs_logit"] = float(np.abs(out["ibs_logits"].detach().float().cpu().numpy() - z[f"{kind}/out/ibs_logits"]).max())
+                if not has_grad:
+                    rows.append(row)
+                    print(json.dumps(row), flush=True)
+                    continue
                 names = [str(n) for n in z[f"{kind}/grad/names"]]
                 params = dict(model.named_parameters())
                 gscale = float(z[f"{kind}/grad/global_norm"])

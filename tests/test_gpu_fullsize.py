@@ -117,3 +117,37 @@ def test_overlapped_weight_gradient_launches_are_bit_identical(monkeypatch):
         assert (eng._wg_side is not None) == (flag == "1")
         grads.append(model._flat.grad.clone())
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[1], grads[2])
+
+
+def test_two_piece_weight_gradient_launch_is_bit_identical_and_releases_buckets_early(monkeypatch):
+    """Data-parallel runs cut the grouped weight-gradient launch in two (layers L-1..L/2, then L/2-1..0) so the upper layers'
+    gradient buckets can start their all-reduce while the lower layers are still in backward.  The cut changes neither a
+    product's split nor its summation order: gradients must equal the single launch bit for bit, and the segment callbacks of
+    the upper layers must arrive BEFORE the lower layers' (they used to arrive all at once, after the last layer)."""
+    z, kw, cfg, sd, model = build("cfg3_xattn", "bf16")
+    model.train()
+    x1, x2, y = _inputs(z)
+    one = torch.ones(1, device=DEV)
+    grads, orders = [], []
+    for flag, listen in (("0", False), ("", True), ("1", False)):
+        monkeypatch.setenv("EYEGAZE_WGRAD_PIECES", flag)
+        eng = model.engine(B, 1024, torch.device(DEV))
+        eng.set_state(seed=99, lr=0.0, step=1)
+        eng.forward(x1, x2, y, train=True)
+        seen = []
+        calls_at = {}
+
+        def on_segment(name):
+            from eyegaze_multimodal_amd import _lib
+            seen.append(name)
+            calls_at[name] = _lib.CALLS
+        eng.backward(gloss=one, on_segment=(on_segment if listen else None))
+        torch.cuda.synchronize()
+        grads.append(model._flat.grad.clone())
+        orders.append((seen, calls_at))
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+    seen, calls_at = orders[1]
+    L_ = cfg.num_layers
+    assert seen == ["heads", "cross", "encoder.norm"] + [f"layer{l}" for l in reversed(range(L_))] + ["frontend"]
+    # launches were issued between the release of layer L/2 and the release of layer L/2-1 (the lower half's backward)
+    assert calls_at[f"layer{L_ // 2 - 1}"] - calls_at[f"layer{L_ // 2}"] > 10

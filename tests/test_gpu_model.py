@@ -19,7 +19,7 @@ from tests.helpers import load_golden, t  # noqa: E402
 
 DEV = "cuda"
 BASE_CONFIGS = ["cfg1_a1_2class", "cfg2_concat", "cfg3_xattn", "tiny_a1"]
-TOKEN_CONFIGS = ["cfg5_a2_spec", "a3_ibs_scalar", "a5_full", "b1_no_inorm", "b2_phase", "b3_amplitude", "tiny_full"]
+TOKEN_CONFIGS = ["cfg5_a2_spec", "a3_ibs_scalar", "a5_full", "b1_no_inorm", "b2_phase", "b3_amplitude", "tiny_full", "a5_c32"]
 ALL = BASE_CONFIGS + TOKEN_CONFIGS
 
 
