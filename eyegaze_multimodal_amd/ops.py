@@ -49,19 +49,18 @@ def dual_eeg_forward(eeg1: torch.Tensor, eeg2: torch.Tensor, labels: Optional[to
     model = owner(handle)
     eng = model.engine(eeg1.shape[0], eeg1.shape[2], eeg1.device)
     out = model._run_forward(eng, eeg1, eeg2, labels, train)
-    empty = eeg1.new_empty(0)
-    return [out.get(k, empty) for k in OUTPUT_KEYS]
+    return [out[k] if k in out else eeg1.new_empty(0) for k in OUTPUT_KEYS]   # (outputs of an operator may not alias each other)
 
 
 @dual_eeg_forward.register_fake
 def _(eeg1, eeg2, labels, params, handle, train):
     model = owner(handle)
     B, d, nc = eeg1.shape[0], model.cfg.d_model, model.cfg.num_classes
-    e = eeg1.new_empty(0)
+    e = lambda: eeg1.new_empty(0)
     ibs, lab = model.cfg.use_ibs, labels is not None
     return [eeg1.new_empty(B, nc), eeg1.new_empty(B, d), eeg1.new_empty(B, d),
-            eeg1.new_empty(B, nc) if ibs else e, eeg1.new_empty(B, d) if ibs else e,
-            eeg1.new_empty(()) if lab else e, eeg1.new_empty(()) if (lab and ibs) else e]
+            eeg1.new_empty(B, nc) if ibs else e(), eeg1.new_empty(B, d) if ibs else e(),
+            eeg1.new_empty(()) if lab else e(), eeg1.new_empty(()) if (lab and ibs) else e()]
 
 
 def _setup(ctx, inputs, output):
