@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=256, help="windows pairs per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay captured hipGraphs instead of eager launches")
     ap.add_argument("--eager", action="store_true", help="(default) accepted for compatibility")

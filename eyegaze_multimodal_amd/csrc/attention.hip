@@ -13,21 +13,27 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-__device__ __forceinline__ bf16x8 ld_frag_global(const bf16_t* p, bool valid) {
+// T = bf16_t or f16_t: the 16-bit storage type; FR<T> = its MFMA operand fragment (8 elements per lane)
+template <typename T> using FR = typename H16<T>::frag;
+
+template <typename T>
+__device__ __forceinline__ FR<T> ld_frag_global(const T* p, bool valid) {
   u32x4 v = {0u, 0u, 0u, 0u};
   if (valid) v = *(const u32x4*)p;
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(FR<T>, v);
 }
 // LDS image: [rows][32 bf16] = 64-B rows; the two 32-B halves of a row are swapped when (row>>2)&1 so that the
 // transposed reads of 8 consecutive rows hit 8 distinct 32-B slots of the 256-B bank row.
 __device__ __forceinline__ int img_chunk_off(int row, int c4) {
   return row * 64 + ((((c4 >> 1) ^ ((row >> 2) & 1))) << 5) + ((c4 & 1) << 4);
 }
-__device__ __forceinline__ bf16x8 ld_frag_lds_row(const char* img, int row, int g) {
-  return *(const bf16x8*)(img + img_chunk_off(row, g));
+template <typename T>
+__device__ __forceinline__ FR<T> ld_frag_lds_row(const char* img, int row, int g) {
+  return *(const FR<T>*)(img + img_chunk_off(row, g));
 }
 // transposed fragment: slot 8g+j <-> row rbase + 16*(j>>2) + 4g + (j&3), column d0 + (lane&15)
-__device__ __forceinline__ bf16x8 ld_frag_lds_tr(const char* img, int rbase, int dt, int lane) {
+template <typename T>
+__device__ __forceinline__ FR<T> ld_frag_lds_tr(const char* img, int rbase, int dt, int lane) {
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
   s16x4 part[2];
 #pragma unroll
@@ -37,17 +43,19 @@ __device__ __forceinline__ bf16x8 ld_frag_lds_tr(const char* img, int rbase, int
     part[h2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(img + off));
   }
   s16x8 t = {part[0][0], part[0][1], part[0][2], part[0][3], part[1][0], part[1][1], part[1][2], part[1][3]};
-  return __builtin_bit_cast(bf16x8, t);
+  return __builtin_bit_cast(FR<T>, t);
 }
-__device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
+template <typename T>
+__device__ __forceinline__ FR<T> pack_frag(const f32x4& a, const f32x4& b) {
   u32x4 v;
-  v[0] = pack2bf(a[0], a[1]);
-  v[1] = pack2bf(a[2], a[3]);
-  v[2] = pack2bf(b[0], b[1]);
-  v[3] = pack2bf(b[2], b[3]);
-  return __builtin_bit_cast(bf16x8, v);
+  v[0] = H16<T>::pack2(a[0], a[1]);
+  v[1] = H16<T>::pack2(a[2], a[3]);
+  v[2] = H16<T>::pack2(b[0], b[1]);
+  v[3] = H16<T>::pack2(b[2], b[3]);
+  return __builtin_bit_cast(FR<T>, v);
 }
-__device__ __forceinline__ void stage_rows(char* img, const bf16_t* src, long long ld, int S, int SP, int first, int step) {
+template <typename T>
+__device__ __forceinline__ void stage_rows(char* img, const T* src, long long ld, int S, int SP, int first, int step) {
   for (int id = first; id < SP * 4; id += step) {
     const int row = id >> 2, c4 = id & 3;
     u32x4 v = {0u, 0u, 0u, 0u};
@@ -58,8 +66,8 @@ __device__ __forceinline__ void stage_rows(char* img, const bf16_t* src, long lo
 
 constexpr float kScale = 0.17677669529663687f;  // 1/sqrt(32)
 
-template <int SP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+template <typename T, int SP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ ctx,
                                                        float* __restrict__ lse, int NB, int S, int H, int kv_shift,
                                                        DropCfg dc, const eg_step_state* st) {
   constexpr int NKT = SP / 16;
@@ -74,31 +82,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const int bk = (b + kv_shift) % NB;
   const int D = H * 32;
   const long long ld = 3ll * D;
-  const bf16_t* qbase = qkv + (long long)b * S * ld + h * 32;
-  const bf16_t* kbase = qkv + (long long)bk * S * ld + D + h * 32;
-  const bf16_t* vbase = kbase + D;
+  const T* qbase = qkv + (long long)b * S * ld + h * 32;
+  const T* kbase = qkv + (long long)bk * S * ld + D + h * 32;
+  const T* vbase = kbase + D;
   char* vimg = smem + (wave >> 1) * (SP * 64);
-  stage_rows(vimg, vbase, ld, S, SP, lane + 64 * role, 128);
+  stage_rows<T>(vimg, vbase, ld, S, SP, lane + 64 * role, 128);
   const int nkt = (S + 15) >> 4;
-  bf16x8 kf[NKT];
+  FR<T> kf[NKT];
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
     const int key = kt * 16 + l15;
-    kf[kt] = ld_frag_global(kbase + (long long)key * ld + g * 8, key < S);
+    kf[kt] = ld_frag_global<T>(kbase + (long long)key * ld + g * 8, key < S);
   }
   uint32_t seed_lo = 0, seed_hi = 0;
   if (dc.thresh) { seed_lo = st->seed_lo; seed_hi = st->seed_hi; }
   __syncthreads();
   for (int qt = role; qt < nkt; qt += 2) {
     const int q = qt * 16 + l15;
-    const bf16x8 qf = ld_frag_global(qbase + (long long)q * ld + g * 8, q < S);
+    const FR<T> qf = ld_frag_global<T>(qbase + (long long)q * ld + g * 8, q < S);
     f32x4 s[NKT];
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (kt < nkt) {   // wave-uniform: key tiles beyond the sequence cost nothing (S = 65 uses 5 of the 6 tiles)
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf, s[kt], 0, 0, 0);
+        s[kt] = H16<T>::mfma(kf[kt], qf, s[kt]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + 4 * g + r;
@@ -142,11 +150,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int kp = 0; kp < NKT / 2; ++kp) {
       if (2 * kp < nkt) {
-        const bf16x8 pf = pack_frag(s[2 * kp], s[2 * kp + 1]);
+        const FR<T> pf = pack_frag<T>(s[2 * kp], s[2 * kp + 1]);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 vf = ld_frag_lds_tr(vimg, 32 * kp, dt, lane);
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+          const FR<T> vf = ld_frag_lds_tr<T>(vimg, 32 * kp, dt, lane);
+          o[dt] = H16<T>::mfma(vf, pf, o[dt]);
         }
       }
     }
@@ -160,10 +168,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   }
 }
 
-template <int SP>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ctx,
-                                                       const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
-                                                       bf16_t* __restrict__ dqkv, int NB, int S, int H, int kv_shift,
+template <typename T, int SP>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ ctx,
+                                                       const T* __restrict__ dctx, const float* __restrict__ lse,
+                                                       T* __restrict__ dqkv, int NB, int S, int H, int kv_shift,
                                                        DropCfg dc, const eg_step_state* st) {
   constexpr int NKT = SP / 16;
   constexpr int WB = 3 * SP * 64 + 2 * SP * 4;
@@ -179,20 +187,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
   const int bk = (b + kv_shift) % NB;
   const int D = H * 32;
   const long long ld = 3ll * D;
-  const bf16_t* qbase = qkv + (long long)b * S * ld + h * 32;
-  const bf16_t* kbase = qkv + (long long)bk * S * ld + D + h * 32;
-  const bf16_t* vbase = kbase + D;
-  const bf16_t* dobase = dctx + (long long)b * S * D + h * 32;
-  const bf16_t* obase = ctx + (long long)b * S * D + h * 32;
+  const T* qbase = qkv + (long long)b * S * ld + h * 32;
+  const T* kbase = qkv + (long long)bk * S * ld + D + h * 32;
+  const T* vbase = kbase + D;
+  const T* dobase = dctx + (long long)b * S * D + h * 32;
+  const T* obase = ctx + (long long)b * S * D + h * 32;
   char* base = smem + (wave >> 1) * WB;
   char* qimg = base;
   char* kimg = base + SP * 64;
   char* doimg = base + 2 * SP * 64;
   float* lsel = (float*)(base + 3 * SP * 64);
   float* dl = lsel + SP;
-  stage_rows(qimg, qbase, ld, S, SP, lane + 64 * role, 128);
-  stage_rows(kimg, kbase, ld, S, SP, lane + 64 * role, 128);
-  stage_rows(doimg, dobase, D, S, SP, lane + 64 * role, 128);
+  stage_rows<T>(qimg, qbase, ld, S, SP, lane + 64 * role, 128);
+  stage_rows<T>(kimg, kbase, ld, S, SP, lane + 64 * role, 128);
+  stage_rows<T>(doimg, dobase, D, S, SP, lane + 64 * role, 128);
   for (int q = lane + 64 * role; q < SP; q += 128) {
     float l = 0.f, dsum = 0.f;
     if (q < S) {
@@ -210,12 +218,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     dl[q] = dsum;
   }
   const int nkt = (S + 15) >> 4;
-  bf16x8 kf[NKT], vf[NKT];
+  FR<T> kf[NKT], vf[NKT];
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
     const int key = kt * 16 + l15;
-    kf[kt] = ld_frag_global(kbase + (long long)key * ld + g * 8, key < S);
-    vf[kt] = ld_frag_global(vbase + (long long)key * ld + g * 8, key < S);
+    kf[kt] = ld_frag_global<T>(kbase + (long long)key * ld + g * 8, key < S);
+    vf[kt] = ld_frag_global<T>(vbase + (long long)key * ld + g * 8, key < S);
   }
   uint32_t seed_lo = 0, seed_hi = 0;
   if (dc.thresh) { seed_lo = st->seed_lo; seed_hi = st->seed_hi; }
@@ -226,8 +234,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
   const int kt_split = (3 * nkt + 2) / 5;   // role 1 takes k-tiles [0, kt_split), role 0 the rest after pass A
   for (int qt = 0; qt < (role == 0 ? nkt : 0); ++qt) {
     const int q = qt * 16 + l15;
-    const bf16x8 qf = ld_frag_lds_row(qimg, q, g);
-    const bf16x8 dof = ld_frag_lds_row(doimg, q, g);
+    const FR<T> qf = ld_frag_lds_row<T>(qimg, q, g);
+    const FR<T> dof = ld_frag_lds_row<T>(doimg, q, g);
     const float lq = lsel[q], dq = dl[q];
     const uint32_t Sp2 = (uint32_t)((S + 1) & ~1);
     const uint32_t rowidx = (headidx + (uint32_t)q) * Sp2;
@@ -237,8 +245,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
       ds[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (kt < nkt) {
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 sT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf, z, 0, 0, 0);
-        const f32x4 dpT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kt], dof, z, 0, 0, 0);
+        const f32x4 sT = H16<T>::mfma(kf[kt], qf, z);
+        const f32x4 dpT = H16<T>::mfma(vf[kt], dof, z);
         float dpv[4] = {dpT[0], dpT[1], dpT[2], dpT[3]};
         eg_dropout_run<4>(dpv, dc, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g));
 #pragma unroll
@@ -253,11 +261,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int kp = 0; kp < NKT / 2; ++kp) {
       if (2 * kp < nkt) {
-        const bf16x8 dsf = pack_frag(ds[2 * kp], ds[2 * kp + 1]);
+        const FR<T> dsf = pack_frag<T>(ds[2 * kp], ds[2 * kp + 1]);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 ktr = ld_frag_lds_tr(kimg, 32 * kp, dt, lane);
-          acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr, dsf, acc[dt], 0, 0, 0);
+          const FR<T> ktr = ld_frag_lds_tr<T>(kimg, 32 * kp, dt, lane);
+          acc[dt] = H16<T>::mfma(ktr, dsf, acc[dt]);
         }
       }
     }
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     f32x4 dk[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     f32x4 dv[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     // kf/vf are indexed with a runtime kt here: pick the fragment with a uniform select chain (no scratch)
-    bf16x8 kfr = kf[0], vfr = vf[0];
+    FR<T> kfr = kf[0], vfr = vf[0];
 #pragma unroll
     for (int i = 1; i < NKT; ++i)
       if (i == kt) { kfr = kf[i]; vfr = vf[i]; }
@@ -290,11 +298,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
           pd2[h2] = (f32x4){0.f, 0.f, 0.f, 0.f};
           ds2[h2] = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (qt < nkt) {
-            const bf16x8 qrow = ld_frag_lds_row(qimg, qt * 16 + l15, g);
-            const bf16x8 dorow = ld_frag_lds_row(doimg, qt * 16 + l15, g);
+            const FR<T> qrow = ld_frag_lds_row<T>(qimg, qt * 16 + l15, g);
+            const FR<T> dorow = ld_frag_lds_row<T>(doimg, qt * 16 + l15, g);
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qrow, kfr, z, 0, 0, 0);
-            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dorow, vfr, z, 0, 0, 0);
+            const f32x4 s = H16<T>::mfma(qrow, kfr, z);
+            const f32x4 dp = H16<T>::mfma(dorow, vfr, z);
             const f32x4 l4 = *(const f32x4*)(lsel + qt * 16 + 4 * g);
             const f32x4 d4 = *(const f32x4*)(dl + qt * 16 + 4 * g);
             const uint32_t Sp2b = (uint32_t)((S + 1) & ~1);
@@ -309,14 +317,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
             }
           }
         }
-        const bf16x8 pdf = pack_frag(pd2[0], pd2[1]);
-        const bf16x8 dsf = pack_frag(ds2[0], ds2[1]);
+        const FR<T> pdf = pack_frag<T>(pd2[0], pd2[1]);
+        const FR<T> dsf = pack_frag<T>(ds2[0], ds2[1]);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 dotr = ld_frag_lds_tr(doimg, 32 * qp, dt, lane);
-          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr, pdf, dv[dt], 0, 0, 0);
-          const bf16x8 qtr = ld_frag_lds_tr(qimg, 32 * qp, dt, lane);
-          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr, dsf, dk[dt], 0, 0, 0);
+          const FR<T> dotr = ld_frag_lds_tr<T>(doimg, 32 * qp, dt, lane);
+          dv[dt] = H16<T>::mfma(dotr, pdf, dv[dt]);
+          const FR<T> qtr = ld_frag_lds_tr<T>(qimg, 32 * qp, dt, lane);
+          dk[dt] = H16<T>::mfma(qtr, dsf, dk[dt]);
         }
       }
     }
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
       for (int dt = 0; dt < 2; ++dt) {
         float a[4] = {dk[dt][0] * kScale, dk[dt][1] * kScale, dk[dt][2] * kScale, dk[dt][3] * kScale};
         float c[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
-        bf16_t* row = dqkv + ((long long)bk * S + key) * ld + h * 32 + 16 * dt + 4 * g;
+        T* row = dqkv + ((long long)bk * S + key) * ld + h * 32 + 16 * dt + 4 * g;
         store4(row + D, a);
         store4(row + 2 * D, c);
       }
@@ -455,26 +463,26 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(const float* __restri
   }
 }
 
-template <int SP>
+template <typename T, int SP>
 int launch_fwd(const void* qkv, void* ctx, float* lse, int NB, int S, int H, int kv_shift, DropCfg dc,
                const eg_step_state* st, hipStream_t s) {
   const int nblk = (NB * H + 1) / 2;
-  hipLaunchKernelGGL(attn_fwd_kernel<SP>, dim3(nblk), dim3(256), 2 * SP * 64, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse,
+  hipLaunchKernelGGL((attn_fwd_kernel<T, SP>), dim3(nblk), dim3(256), 2 * SP * 64, s, (const T*)qkv, (T*)ctx, lse,
                      NB, S, H, kv_shift, dc, st);
   return 0;
 }
-template <int SP>
+template <typename T, int SP>
 int launch_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int NB, int S, int H,
                int kv_shift, DropCfg dc, const eg_step_state* st, hipStream_t s) {
   const int nblk = (NB * H + 1) / 2;
   constexpr int lds = 2 * (3 * SP * 64 + 2 * SP * 4);
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)attn_bwd_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel<SP>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                     (const bf16_t*)dctx, lse, (bf16_t*)dqkv, NB, S, H, kv_shift, dc, st);
+  hipLaunchKernelGGL((attn_bwd_kernel<T, SP>), dim3(nblk), dim3(256), lds, s, (const T*)qkv, (const T*)ctx,
+                     (const T*)dctx, lse, (T*)dqkv, NB, S, H, kv_shift, dc, st);
   return 0;
 }
 
@@ -484,7 +492,7 @@ static int attn_check(const char* who, int NB, int S, int H, int kv_shift, int d
   EG_CHECK(NB > 0 && S > 0 && H > 0, "%s: bad shape NB=%d S=%d H=%d", who, NB, S, H);
   EG_CHECK(S <= 160, "%s: S=%d exceeds the register-resident limit of 160", who, S);
   EG_CHECK(kv_shift >= 0 && kv_shift < NB, "%s: kv_shift=%d out of range", who, kv_shift);
-  EG_CHECK(dtype == EG_BF16 || dtype == EG_F32, "%s: bad dtype %d", who, dtype);
+  EG_CHECK(dtype == EG_BF16 || dtype == EG_F32 || dtype == EG_F16, "%s: bad dtype %d", who, dtype);
   EG_CHECK(p >= 0.f && p < 1.f && (p == 0.f || st), "%s: dropout p=%f needs a step state", who, (double)p);
   EG_CHECK((long long)NB * H * S * (S + 1) < (1ll << 32), "%s: NB*H*S*S exceeds the 32-bit dropout index", who);
   return 0;
@@ -502,9 +510,15 @@ extern "C" int eg_attention_fwd(const void* qkv, void* ctx, float* lse, int NB, 
     EG_LAUNCH_CHECK("attention_fwd_f32");
     return 0;
   }
-  if (S <= 96) launch_fwd<96>(qkv, ctx, lse, NB, S, H, kv_shift, dc, state, s);
-  else if (S <= 128) launch_fwd<128>(qkv, ctx, lse, NB, S, H, kv_shift, dc, state, s);
-  else launch_fwd<160>(qkv, ctx, lse, NB, S, H, kv_shift, dc, state, s);
+  if (dtype == EG_F16) {
+    if (S <= 96) launch_fwd<f16_t, 96>(qkv, ctx, lse, NB, S, H, kv_shift, dc, state, s);
+    else if (S <= 128) launch_fwd<f16_t, 128>(qkv, ctx, lse, NB, S, H, kv_shift, dc, state, s);
+    else launch_fwd<f16_t, 160>(qkv, ctx, lse, NB, S, H, kv_shift, dc, state, s);
+  } else {
+    if (S <= 96) launch_fwd<bf16_t, 96>(qkv, ctx, lse, NB, S, H, kv_shift, dc, state, s);
+    else if (S <= 128) launch_fwd<bf16_t, 128>(qkv, ctx, lse, NB, S, H, kv_shift, dc, state, s);
+    else launch_fwd<bf16_t, 160>(qkv, ctx, lse, NB, S, H, kv_shift, dc, state, s);
+  }
   EG_LAUNCH_CHECK("attention_fwd");
   return 0;
 }
@@ -528,9 +542,15 @@ extern "C" int eg_attention_bwd(const void* qkv, const void* ctx, const void* dc
     EG_LAUNCH_CHECK("attention_bwd_f32");
     return 0;
   }
-  if (S <= 96) launch_bwd<96>(qkv, ctx, dctx, lse, dqkv, NB, S, H, kv_shift, dc, state, s);
-  else if (S <= 128) launch_bwd<128>(qkv, ctx, dctx, lse, dqkv, NB, S, H, kv_shift, dc, state, s);
-  else launch_bwd<160>(qkv, ctx, dctx, lse, dqkv, NB, S, H, kv_shift, dc, state, s);
+  if (dtype == EG_F16) {
+    if (S <= 96) launch_bwd<f16_t, 96>(qkv, ctx, dctx, lse, dqkv, NB, S, H, kv_shift, dc, state, s);
+    else if (S <= 128) launch_bwd<f16_t, 128>(qkv, ctx, dctx, lse, dqkv, NB, S, H, kv_shift, dc, state, s);
+    else launch_bwd<f16_t, 160>(qkv, ctx, dctx, lse, dqkv, NB, S, H, kv_shift, dc, state, s);
+  } else {
+    if (S <= 96) launch_bwd<bf16_t, 96>(qkv, ctx, dctx, lse, dqkv, NB, S, H, kv_shift, dc, state, s);
+    else if (S <= 128) launch_bwd<bf16_t, 128>(qkv, ctx, dctx, lse, dqkv, NB, S, H, kv_shift, dc, state, s);
+    else launch_bwd<bf16_t, 160>(qkv, ctx, dctx, lse, dqkv, NB, S, H, kv_shift, dc, state, s);
+  }
   EG_LAUNCH_CHECK("attention_bwd");
   return 0;
 }
@@ -572,6 +592,8 @@ extern "C" int eg_attention_probs(const void* qkv, const float* lse, float* prob
   hipStream_t s = (hipStream_t)stream;
   if (dtype == EG_F32)
     hipLaunchKernelGGL(attn_probs_kernel<float>, dim3(NB * H), dim3(256), lds, s, (const float*)qkv, lse, probs, NB, S, H, kv_shift);
+  else if (dtype == EG_F16)
+    hipLaunchKernelGGL(attn_probs_kernel<f16_t>, dim3(NB * H), dim3(256), lds, s, (const f16_t*)qkv, lse, probs, NB, S, H, kv_shift);
   else
     hipLaunchKernelGGL(attn_probs_kernel<bf16_t>, dim3(NB * H), dim3(256), lds, s, (const bf16_t*)qkv, lse, probs, NB, S, H, kv_shift);
   EG_LAUNCH_CHECK("attention_probs");

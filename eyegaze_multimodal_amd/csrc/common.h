@@ -14,6 +14,12 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 typedef uint16_t bf16_t;  // storage type for bf16 tensors
+// storage type for fp16 tensors: a distinct C++ type, so that overloads / templates pick the IEEE-half conversions and the
+// f16 MFMA (v_mfma_f32_16x16x32_f16) wherever the bf16 path picks its own
+struct f16_t { uint16_t bits; };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define EG_WAVE 64
 
@@ -42,6 +48,31 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float h2f(uint16_t bits) { return (float)__builtin_bit_cast(_Float16, bits); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }   // round-to-nearest-even
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){lo, hi}, f16x2));
+}
+
+// 16-bit operand traits: MFMA fragment type, the 16x16x32 MFMA, packing and rounding of the storage type
+template <typename T> struct H16;
+template <> struct H16<bf16_t> {
+  typedef bf16x8 frag;
+  __device__ static __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) { return pack2bf(lo, hi); }
+  __device__ static __forceinline__ float ld(bf16_t v) { return bf2f(v); }
+  __device__ static __forceinline__ float round(float v) { return bf2f(f2bf(v)); }
+};
+template <> struct H16<f16_t> {
+  typedef f16x8 frag;
+  __device__ static __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) { return pack2h(lo, hi); }
+  __device__ static __forceinline__ float ld(f16_t v) { return h2f(v.bits); }
+  __device__ static __forceinline__ float round(float v) { return h2f(f2h(v)); }
+};
+// rounding through the storage type (identity for fp32): what a stored element reads back as
+template <typename T> __device__ __forceinline__ float round_store(float v) { return H16<T>::round(v); }
+template <> __device__ __forceinline__ float round_store<float>(float v) { return v; }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -53,6 +84,11 @@ template <> struct Elem<bf16_t> {
   static constexpr int kPer16B = 8;
   __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
   __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+template <> struct Elem<f16_t> {
+  static constexpr int kPer16B = 8;
+  __device__ static __forceinline__ float ld(const f16_t* p) { return h2f(p->bits); }
+  __device__ static __forceinline__ void st(f16_t* p, float v) { p->bits = f2h(v); }
 };
 
 // load / store 8 consecutive elements as floats (pointer must be 16-B aligned for bf16, 32-B region for f32)
@@ -67,6 +103,36 @@ __device__ __forceinline__ void load8(const bf16_t* p, float v[8]) {
     v[2 * i] = __uint_as_float(a[i] << 16);
     v[2 * i + 1] = __uint_as_float(a[i] & 0xffff0000u);
   }
+}
+__device__ __forceinline__ void load8(const f16_t* p, float v[8]) {
+  u32x4 a = *(const u32x4*)p;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 t = __builtin_convertvector(__builtin_bit_cast(f16x2, a[i]), f32x2);
+    v[2 * i] = t[0];
+    v[2 * i + 1] = t[1];
+  }
+}
+__device__ __forceinline__ void store8(f16_t* p, const float v[8]) {
+  u32x4 a;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = pack2h(v[2 * i], v[2 * i + 1]);
+  *(u32x4*)p = a;
+}
+__device__ __forceinline__ void load4(const f16_t* p, float v[4]) {
+  u32x2 a = *(const u32x2*)p;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const f32x2 t = __builtin_convertvector(__builtin_bit_cast(f16x2, a[i]), f32x2);
+    v[2 * i] = t[0];
+    v[2 * i + 1] = t[1];
+  }
+}
+__device__ __forceinline__ void store4(f16_t* p, const float v[4]) {
+  u32x2 a;
+  a[0] = pack2h(v[0], v[1]);
+  a[1] = pack2h(v[2], v[3]);
+  *(u32x2*)p = a;
 }
 __device__ __forceinline__ void store8(float* p, const float v[8]) {
   f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};

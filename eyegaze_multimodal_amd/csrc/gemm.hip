@@ -32,26 +32,22 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 template <typename T>
-__device__ __forceinline__ void mma_ktile(const char* bufA, const char* bufW, int wm, int wn, int lane, f32x4 (&acc)[4][4]);
-
-template <>
-__device__ __forceinline__ void mma_ktile<bf16_t>(const char* bufA, const char* bufW, int wm, int wn, int lane,
-                                                  f32x4 (&acc)[4][4]) {
+__device__ __forceinline__ void mma_ktile(const char* bufA, const char* bufW, int wm, int wn, int lane, f32x4 (&acc)[4][4]) {
+  typedef typename H16<T>::frag frag;          // 16-bit operands (bf16 / fp16): K-tile 64, 2 MFMA k-steps
   const int l15 = lane & 15, g = lane >> 4, sw = lane & 7;
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
     const int ch = ((kk * 4 + g) ^ sw) << 4;
-    bf16x8 xf[4], wf[4];
+    frag xf[4], wf[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      xf[i] = *(const bf16x8*)(bufA + (wm * 64 + i * 16 + l15) * 128 + ch);
-      wf[i] = *(const bf16x8*)(bufW + (wn * 64 + i * 16 + l15) * 128 + ch);
+      xf[i] = *(const frag*)(bufA + (wm * 64 + i * 16 + l15) * 128 + ch);
+      wf[i] = *(const frag*)(bufW + (wn * 64 + i * 16 + l15) * 128 + ch);
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+      for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = H16<T>::mfma(wf[ni], xf[mi], acc[ni][mi]);
   }
 }
 
@@ -256,10 +252,13 @@ struct GemmRow {
 // 8 consecutive elements held raw (16 B for 16-bit types, 32 B for fp32) so loads can be issued long before their use
 template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> { u32x4 a; };
+template <> struct Raw8<f16_t> { u32x4 a; };
 template <> struct Raw8<float> { f32x4 a, b; };
 __device__ __forceinline__ Raw8<bf16_t> ldraw8(const bf16_t* p) { Raw8<bf16_t> r; r.a = *(const u32x4*)p; return r; }
+__device__ __forceinline__ Raw8<f16_t> ldraw8(const f16_t* p) { Raw8<f16_t> r; r.a = *(const u32x4*)p; return r; }
 __device__ __forceinline__ Raw8<float> ldraw8(const float* p) { Raw8<float> r; r.a = *(const f32x4*)p; r.b = *(const f32x4*)(p + 4); return r; }
 __device__ __forceinline__ void cvt8(const Raw8<bf16_t>& r, float v[8]) { load8((const bf16_t*)&r.a, v); }
+__device__ __forceinline__ void cvt8(const Raw8<f16_t>& r, float v[8]) { load8((const f16_t*)&r.a, v); }
 __device__ __forceinline__ void cvt8(const Raw8<float>& r, float v[8]) {
   v[0] = r.a[0]; v[1] = r.a[1]; v[2] = r.a[2]; v[3] = r.a[3]; v[4] = r.b[0]; v[5] = r.b[1]; v[6] = r.b[2]; v[7] = r.b[3];
 }
@@ -389,7 +388,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void gemm_nt_row_kerne
       if (LN == 1) {
         if (sizeof(T) == 2) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = bf2f(f2bf(v[j]));   // normalise exactly what was stored
+          for (int j = 0; j < 8; ++j) v[j] = round_store<T>(v[j]);   // normalise exactly what was stored
         }
         float s1 = 0.f;
 #pragma unroll
@@ -480,17 +479,16 @@ __device__ __forceinline__ int tn_swz(int r) { return (((r & 3) | ((r >> 1) & 4)
 
 template <typename T> struct TNCfg;
 template <> struct TNCfg<bf16_t> { static constexpr int ROWB = 256; static constexpr int CHUNKS = 16; static constexpr int STAGE_ROWS = 64; };
+template <> struct TNCfg<f16_t> { static constexpr int ROWB = 256; static constexpr int CHUNKS = 16; static constexpr int STAGE_ROWS = 64; };
 template <> struct TNCfg<float> { static constexpr int ROWB = 512; static constexpr int CHUNKS = 32; static constexpr int STAGE_ROWS = 32; };
 
 template <typename T>
-__device__ __forceinline__ void tn_mma(const char* bufY, const char* bufX, int wn, int wk, int lane, f32x4 (&acc)[4][4]);
-
-template <>
-__device__ __forceinline__ void tn_mma<bf16_t>(const char* bufY, const char* bufX, int wn, int wk, int lane,
+__device__ __forceinline__ void tn_mma(const char* bufY, const char* bufX, int wn, int wk, int lane,
                                                f32x4 (&acc)[4][4]) {
   // lane (g = lane>>4, q = (lane&15)>>2, p = lane&3) addresses row 8g+4h+q, columns base+4p..4p+3
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-  bf16x8 yf[4], xf[4];
+  typedef typename H16<T>::frag frag;
+  frag yf[4], xf[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     s16x4 lo[2], hi[2];
@@ -508,14 +506,14 @@ __device__ __forceinline__ void tn_mma<bf16_t>(const char* bufY, const char* buf
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     s16x8 ty = {lo[0][0], lo[0][1], lo[0][2], lo[0][3], lo[1][0], lo[1][1], lo[1][2], lo[1][3]};
     s16x8 tx = {hi[0][0], hi[0][1], hi[0][2], hi[0][3], hi[1][0], hi[1][1], hi[1][2], hi[1][3]};
-    yf[i] = __builtin_bit_cast(bf16x8, ty);
-    xf[i] = __builtin_bit_cast(bf16x8, tx);
+    yf[i] = __builtin_bit_cast(frag, ty);
+    xf[i] = __builtin_bit_cast(frag, tx);
   }
 #pragma unroll
   for (int ki = 0; ki < 4; ++ki)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
-      acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ki], yf[ni], acc[ki][ni], 0, 0, 0);
+      acc[ki][ni] = H16<T>::mfma(xf[ki], yf[ni], acc[ki][ni]);
 }
 
 template <>
@@ -543,14 +541,12 @@ __device__ __forceinline__ void tn_mma<float>(const char* bufY, const char* bufX
 
 // column sums of the dY tile (rows 16*half .. +15, column `col`) straight from its swizzled LDS image
 template <typename T>
-__device__ __forceinline__ float tn_tile_colsum(const char* bufY, int col, int half);
-template <>
-__device__ __forceinline__ float tn_tile_colsum<bf16_t>(const char* bufY, int col, int half) {
+__device__ __forceinline__ float tn_tile_colsum(const char* bufY, int col, int half) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int r = half * 16 + i;
-    s += bf2f(*(const bf16_t*)(bufY + r * 256 + (((col >> 3) ^ tn_swz(r)) << 4) + (col & 7) * 2));
+    s += H16<T>::ld(*(const T*)(bufY + r * 256 + (((col >> 3) ^ tn_swz(r)) << 4) + (col & 7) * 2));
   }
   return s;
 }
@@ -898,9 +894,9 @@ int eg_rs_gemm_try(const eg_gemm_desc* d, hipStream_t s);   // rsgemm.hip: regis
 extern "C" int eg_gemm_nt(const eg_gemm_desc* d, void* stream) {
   EG_CHECK(d && d->A && d->W && (d->C || d->ln_mode == 2), "eg_gemm_nt: null operand");
   EG_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "eg_gemm_nt: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
-  EG_CHECK(d->dtype == EG_F32 || d->dtype == EG_BF16, "eg_gemm_nt: bad dtype %d", d->dtype);
-  const int bk = d->dtype == EG_BF16 ? 64 : 32;
-  const int al = d->dtype == EG_BF16 ? 8 : 4;  // elements per 16 B
+  EG_CHECK(d->dtype == EG_F32 || d->dtype == EG_BF16 || d->dtype == EG_F16, "eg_gemm_nt: bad dtype %d", d->dtype);
+  const int bk = d->dtype == EG_F32 ? 32 : 64;
+  const int al = d->dtype == EG_F32 ? 4 : 8;  // elements per 16 B
   EG_CHECK(d->K % bk == 0, "eg_gemm_nt: K=%d must be a multiple of %d", d->K, bk);
   EG_CHECK(d->N % 8 == 0, "eg_gemm_nt: N=%d must be a multiple of 8", d->N);
   EG_CHECK(d->ldw >= d->K && d->ldw % al == 0, "eg_gemm_nt: ldw=%d", d->ldw);
@@ -932,9 +928,9 @@ extern "C" int eg_gemm_nt(const eg_gemm_desc* d, void* stream) {
       EG_CHECK((d->ln_drop1_p == 0.f && d->ln_drop2_p == 0.f) || (d->state && d->ln_out2), "eg_gemm_nt: ln dropout needs a step state and ln_out2");
       EG_CHECK(d->ln_drop1_p >= 0.f && d->ln_drop1_p < 1.f && d->ln_drop2_p >= 0.f && d->ln_drop2_p < 1.f, "eg_gemm_nt: ln dropout p");
     }
-    return d->dtype == EG_BF16 ? launch_gemm_row<bf16_t>(d, s) : launch_gemm_row<float>(d, s);
+    return d->dtype == EG_BF16 ? launch_gemm_row<bf16_t>(d, s) : d->dtype == EG_F16 ? launch_gemm_row<f16_t>(d, s) : launch_gemm_row<float>(d, s);
   }
-  return d->dtype == EG_BF16 ? launch_gemm_nt<bf16_t>(d, s) : launch_gemm_nt<float>(d, s);
+  return d->dtype == EG_BF16 ? launch_gemm_nt<bf16_t>(d, s) : d->dtype == EG_F16 ? launch_gemm_nt<f16_t>(d, s) : launch_gemm_nt<float>(d, s);
 }
 
 template <typename T>
@@ -961,9 +957,9 @@ static int launch_gemm_tn(const eg_gemm_tn_desc* d, hipStream_t s) {
 extern "C" int eg_gemm_tn(const eg_gemm_tn_desc* d, void* stream) {
   EG_CHECK(d && d->dY && d->X && d->partial, "eg_gemm_tn: null operand");
   EG_CHECK(d->M > 0 && d->N > 0 && d->K > 0 && d->splits > 0, "eg_gemm_tn: bad shape");
-  EG_CHECK(d->dtype == EG_F32 || d->dtype == EG_BF16, "eg_gemm_tn: bad dtype %d", d->dtype);
+  EG_CHECK(d->dtype == EG_F32 || d->dtype == EG_BF16 || d->dtype == EG_F16, "eg_gemm_tn: bad dtype %d", d->dtype);
   EG_CHECK(d->N % 8 == 0 && d->K % 8 == 0, "eg_gemm_tn: N=%d, K=%d must be multiples of 8", d->N, d->K);
-  const int al = d->dtype == EG_BF16 ? 8 : 4;
+  const int al = d->dtype == EG_F32 ? 4 : 8;
   EG_CHECK(d->y.row_stride % al == 0 && d->y.group_stride % al == 0 && d->x.row_stride % al == 0 &&
                d->x.group_stride % al == 0, "eg_gemm_tn: rows must be 16-B aligned");
   EG_CHECK(((uintptr_t)d->dY | (uintptr_t)d->X | (uintptr_t)d->partial) % 16 == 0, "eg_gemm_tn: alignment");
@@ -971,7 +967,7 @@ extern "C" int eg_gemm_tn(const eg_gemm_tn_desc* d, void* stream) {
   EG_CHECK(!d->has_bias || d->K % 4 == 0, "eg_gemm_tn: fused bias sums need K %% 4 == 0");
   EG_CHECK(d->x_tile_stride == 0 || (d->x_tile_stride % al == 0 && d->K % 128 == 0), "eg_gemm_tn: x_tile_stride needs K %% 128 == 0");
   hipStream_t s = (hipStream_t)stream;
-  return d->dtype == EG_BF16 ? launch_gemm_tn<bf16_t>(d, s) : launch_gemm_tn<float>(d, s);
+  return d->dtype == EG_BF16 ? launch_gemm_tn<bf16_t>(d, s) : d->dtype == EG_F16 ? launch_gemm_tn<f16_t>(d, s) : launch_gemm_tn<float>(d, s);
 }
 
 extern "C" int eg_reduce_partials(const float* partial, float* out, int64_t n, int splits, int64_t split_stride,
@@ -1005,6 +1001,9 @@ extern "C" int eg_colsum(const void* Y, eg_rowmap y, int M, int N, float* partia
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Y,
                        to_rowmap(y), M, N, rpb, partial);
+  else if (dtype == EG_F16)
+    hipLaunchKernelGGL(colsum_kernel<f16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const f16_t*)Y,
+                       to_rowmap(y), M, N, rpb, partial);
   else if (dtype == EG_F32)
     hipLaunchKernelGGL(colsum_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)Y,
                        to_rowmap(y), M, N, rpb, partial);
@@ -1017,12 +1016,15 @@ extern "C" int eg_colsum(const void* Y, eg_rowmap y, int M, int N, float* partia
 extern "C" int eg_gemm_tn_grouped(const eg_tn_problem* probs, int nprob, int total_blocks, int M, int splits, int dtype,
                                   void* stream) {
   EG_CHECK(probs && nprob > 0 && total_blocks > 0 && M > 0 && splits > 0, "eg_gemm_tn_grouped: bad arguments");
-  EG_CHECK(dtype == EG_F32 || dtype == EG_BF16, "eg_gemm_tn_grouped: bad dtype %d", dtype);
+  EG_CHECK(dtype == EG_F32 || dtype == EG_BF16 || dtype == EG_F16, "eg_gemm_tn_grouped: bad dtype %d", dtype);
   int rps = (M + splits - 1) / splits;
   rps = (rps + 63) / 64 * 64;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(gemm_tn_grouped_kernel<bf16_t>, dim3(total_blocks), dim3(256), 2 * TNCfg<bf16_t>::STAGE_ROWS * TNCfg<bf16_t>::ROWB,
+                       s, probs, nprob, M, splits, rps);
+  else if (dtype == EG_F16)
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel<f16_t>, dim3(total_blocks), dim3(256), 2 * TNCfg<f16_t>::STAGE_ROWS * TNCfg<f16_t>::ROWB,
                        s, probs, nprob, M, splits, rps);
   else
     hipLaunchKernelGGL(gemm_tn_grouped_kernel<float>, dim3(total_blocks), dim3(256), 2 * TNCfg<float>::STAGE_ROWS * TNCfg<float>::ROWB,

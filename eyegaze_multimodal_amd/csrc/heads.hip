@@ -464,8 +464,9 @@ __global__ __launch_bounds__(128) void fuzzy_gate_bwd_kernel(const float* __rest
 
 }  // namespace
 
-#define DISPATCH_T(dtype, CALL_BF16, CALL_F32, who)          \
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F16, CALL_F32, who) \
   if ((dtype) == EG_BF16) { CALL_BF16; }                      \
+  else if ((dtype) == EG_F16) { CALL_F16; }                   \
   else if ((dtype) == EG_F32) { CALL_F32; }                   \
   else return eg_fail("%s: bad dtype %d", who, (int)(dtype));
 
@@ -476,6 +477,7 @@ extern "C" int eg_rows_bcast_f32(const float* src, const float* pos, void* seq, 
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(rows_bcast_f32_kernel<bf16_t>, grid, dim3(256), 0, s, src, pos, (bf16_t*)seq, NB, S, D, R, off, src_nb),
+             hipLaunchKernelGGL(rows_bcast_f32_kernel<f16_t>, grid, dim3(256), 0, s, src, pos, (f16_t*)seq, NB, S, D, R, off, src_nb),
              hipLaunchKernelGGL(rows_bcast_f32_kernel<float>, grid, dim3(256), 0, s, src, pos, (float*)seq, NB, S, D, R, off, src_nb),
              "eg_rows_bcast_f32");
   EG_LAUNCH_CHECK("rows_bcast_f32");
@@ -489,6 +491,7 @@ extern "C" int eg_rows_copy(void* seq, int S, int D, int R, int off, int b_src0,
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(rows_copy_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)seq, S, D, R, off, b_src0, b_dst0),
+             hipLaunchKernelGGL(rows_copy_kernel<f16_t>, grid, dim3(256), 0, s, (f16_t*)seq, S, D, R, off, b_src0, b_dst0),
              hipLaunchKernelGGL(rows_copy_kernel<float>, grid, dim3(256), 0, s, (float*)seq, S, D, R, off, b_src0, b_dst0),
              "eg_rows_copy");
   EG_LAUNCH_CHECK("rows_copy");
@@ -504,6 +507,7 @@ extern "C" int eg_pool_fuse_fwd(const void* z, float* cls1, float* cls2, void* c
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(pool_fuse_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)z, cls1, cls2, (bf16_t*)comb, (bf16_t*)zf, ibs_pool_f, (bf16_t*)ibs_pool, B, S, D, off, n_ibs, ibs_first),
+             hipLaunchKernelGGL(pool_fuse_fwd_kernel<f16_t>, dim3(B), dim3(256), 0, s, (const f16_t*)z, cls1, cls2, (f16_t*)comb, (f16_t*)zf, ibs_pool_f, (f16_t*)ibs_pool, B, S, D, off, n_ibs, ibs_first),
              hipLaunchKernelGGL(pool_fuse_fwd_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)z, cls1, cls2, (float*)comb, (float*)zf, ibs_pool_f, (float*)ibs_pool, B, S, D, off, n_ibs, ibs_first),
              "eg_pool_fuse_fwd");
   EG_LAUNCH_CHECK("pool_fuse_fwd");
@@ -518,6 +522,7 @@ extern "C" int eg_pool_fuse_bwd(const void* z, const void* dcomb, const void* dz
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(pool_fuse_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)z, (const bf16_t*)dcomb, (const bf16_t*)dzf, gcls1, gcls2, (const bf16_t*)dibs_pool, gibs_pool, (bf16_t*)dz, B, S, D, off, n_ibs, ibs_first),
+             hipLaunchKernelGGL(pool_fuse_bwd_kernel<f16_t>, dim3(B), dim3(256), 0, s, (const f16_t*)z, (const f16_t*)dcomb, (const f16_t*)dzf, gcls1, gcls2, (const f16_t*)dibs_pool, gibs_pool, (f16_t*)dz, B, S, D, off, n_ibs, ibs_first),
              hipLaunchKernelGGL(pool_fuse_bwd_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)z, (const float*)dcomb, (const float*)dzf, gcls1, gcls2, (const float*)dibs_pool, gibs_pool, (float*)dz, B, S, D, off, n_ibs, ibs_first),
              "eg_pool_fuse_bwd");
   EG_LAUNCH_CHECK("pool_fuse_bwd");
@@ -534,6 +539,7 @@ extern "C" int eg_classifier_ce_fwd(const void* h, const float* W, const float* 
   dim3 grid((B + 3) / 4);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(classifier_ce_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)h, W, bias, (const long long*)labels, logits, sample_loss, B, K, ncls),
+             hipLaunchKernelGGL(classifier_ce_fwd_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)h, W, bias, (const long long*)labels, logits, sample_loss, B, K, ncls),
              hipLaunchKernelGGL(classifier_ce_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)h, W, bias, (const long long*)labels, logits, sample_loss, B, K, ncls),
              "eg_classifier_ce_fwd");
   if (labels) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, sample_loss, loss, B);
@@ -552,6 +558,8 @@ extern "C" int eg_classifier_ce_bwd(const void* h, const float* W, const float* 
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(classifier_ce_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)h, W, logits, (const long long*)labels, gloss, glogits, dlogits, (bf16_t*)dh, B, K, ncls, use_gate, gate_scale);
              hipLaunchKernelGGL(classifier_wgrad_kernel<bf16_t>, dim3(ncls, (K + 63) / 64), dim3(256), 0, s, (const bf16_t*)h, dlogits, dW, db, B, K, ncls),
+             hipLaunchKernelGGL(classifier_ce_bwd_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)h, W, logits, (const long long*)labels, gloss, glogits, dlogits, (f16_t*)dh, B, K, ncls, use_gate, gate_scale);
+             hipLaunchKernelGGL(classifier_wgrad_kernel<f16_t>, dim3(ncls, (K + 63) / 64), dim3(256), 0, s, (const f16_t*)h, dlogits, dW, db, B, K, ncls),
              hipLaunchKernelGGL(classifier_ce_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)h, W, logits, (const long long*)labels, gloss, glogits, dlogits, (float*)dh, B, K, ncls, use_gate, gate_scale);
              hipLaunchKernelGGL(classifier_wgrad_kernel<float>, dim3(ncls, (K + 63) / 64), dim3(256), 0, s, (const float*)h, dlogits, dW, db, B, K, ncls),
              "eg_classifier_ce_bwd");
@@ -564,6 +572,7 @@ extern "C" int eg_batch_rowsum(const void* dseq, float* out, int NB, int S, int 
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(batch_rowsum_kernel<bf16_t>, dim3(rows, (D + 63) / 64), dim3(256), 0, s, (const bf16_t*)dseq, out, NB, S, D),
+             hipLaunchKernelGGL(batch_rowsum_kernel<f16_t>, dim3(rows, (D + 63) / 64), dim3(256), 0, s, (const f16_t*)dseq, out, NB, S, D),
              hipLaunchKernelGGL(batch_rowsum_kernel<float>, dim3(rows, (D + 63) / 64), dim3(256), 0, s, (const float*)dseq, out, NB, S, D),
              "eg_batch_rowsum");
   EG_LAUNCH_CHECK("batch_rowsum");
@@ -577,6 +586,7 @@ extern "C" int eg_rows_gather_gate(const void* src, const void* gate, void* dst,
   dim3 grid(R, nb);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(rows_gather_gate_kernel<bf16_t>, grid, dim3(64), 0, s, (const bf16_t*)src, (const bf16_t*)gate, (bf16_t*)dst, to_rowmap(dmap), S, D, R, off, pair_shift, gate_scale),
+             hipLaunchKernelGGL(rows_gather_gate_kernel<f16_t>, grid, dim3(64), 0, s, (const f16_t*)src, (const f16_t*)gate, (f16_t*)dst, to_rowmap(dmap), S, D, R, off, pair_shift, gate_scale),
              hipLaunchKernelGGL(rows_gather_gate_kernel<float>, grid, dim3(64), 0, s, (const float*)src, (const float*)gate, (float*)dst, to_rowmap(dmap), S, D, R, off, pair_shift, gate_scale),
              "eg_rows_gather_gate");
   EG_LAUNCH_CHECK("rows_gather_gate");

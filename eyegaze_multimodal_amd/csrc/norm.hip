@@ -260,11 +260,14 @@ extern "C" int eg_layernorm_fwd(const void* x, const float* gamma, const float* 
   EG_CHECK(x && gamma && beta && y, "eg_layernorm_fwd: null pointer");
   EG_CHECK(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "eg_layernorm_fwd: D=%d must be a multiple of 4, <= 1024", D);
   dim3 grid((M + 3) / 4);
-  if (D == 256 && (dtype == EG_BF16 || dtype == EG_F32)) {
+  if (D == 256 && (dtype == EG_BF16 || dtype == EG_F32 || dtype == EG_F16)) {
     dim3 g8((M + 7) / 8);
     if (dtype == EG_BF16)
       hipLaunchKernelGGL(layernorm_fwd256_kernel<bf16_t>, g8, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta,
                          (bf16_t*)y, stats, M);
+    else if (dtype == EG_F16)
+      hipLaunchKernelGGL(layernorm_fwd256_kernel<f16_t>, g8, dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, gamma, beta,
+                         (f16_t*)y, stats, M);
     else
       hipLaunchKernelGGL(layernorm_fwd256_kernel<float>, g8, dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma, beta,
                          (float*)y, stats, M);
@@ -274,6 +277,9 @@ extern "C" int eg_layernorm_fwd(const void* x, const float* gamma, const float* 
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma,
                        beta, (bf16_t*)y, stats, M, D);
+  else if (dtype == EG_F16)
+    hipLaunchKernelGGL(layernorm_fwd_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, gamma,
+                       beta, (f16_t*)y, stats, M, D);
   else if (dtype == EG_F32)
     hipLaunchKernelGGL(layernorm_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma, beta,
                        (float*)y, stats, M, D);
@@ -292,10 +298,13 @@ extern "C" int eg_layernorm_bwd(const void* dy, const void* x, const float* stat
   EG_CHECK((drop1_p == 0.f && drop2_p == 0.f) || state, "eg_layernorm_bwd: dropout needs a step state");
   EG_CHECK((long long)M * D < (1ll << 32), "eg_layernorm_bwd: M*D exceeds the 32-bit dropout index");
   DropCfg d1 = make_drop(drop1_p, drop1_site), d2 = make_drop(drop2_p, drop2_site);
-  if (D == 256 && (dtype == EG_BF16 || dtype == EG_F32)) {
+  if (D == 256 && (dtype == EG_BF16 || dtype == EG_F32 || dtype == EG_F16)) {
     if (dtype == EG_BF16)
       hipLaunchKernelGGL(layernorm_bwd256_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                          (const bf16_t*)x, stats, gamma, (bf16_t*)dx, (bf16_t*)dx_drop, partial, M, d1, d2, state);
+    else if (dtype == EG_F16)
+      hipLaunchKernelGGL(layernorm_bwd256_kernel<f16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const f16_t*)dy,
+                         (const f16_t*)x, stats, gamma, (f16_t*)dx, (f16_t*)dx_drop, partial, M, d1, d2, state);
     else
       hipLaunchKernelGGL(layernorm_bwd256_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
                          (const float*)x, stats, gamma, (float*)dx, (float*)dx_drop, partial, M, d1, d2, state);
@@ -305,6 +314,9 @@ extern "C" int eg_layernorm_bwd(const void* dy, const void* x, const float* stat
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                        (const bf16_t*)x, stats, gamma, (bf16_t*)dx, (bf16_t*)dx_drop, partial, M, D, d1, d2, state);
+  else if (dtype == EG_F16)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<f16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const f16_t*)dy,
+                       (const f16_t*)x, stats, gamma, (f16_t*)dx, (f16_t*)dx_drop, partial, M, D, d1, d2, state);
   else if (dtype == EG_F32)
     hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
                        (const float*)x, stats, gamma, (float*)dx, (float*)dx_drop, partial, M, D, d1, d2, state);

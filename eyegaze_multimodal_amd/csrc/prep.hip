@@ -169,6 +169,8 @@ extern "C" int eg_pack_table(const eg_pack_entry* table, int nentries, int total
   EG_CHECK(table && nentries > 0 && total_blocks > 0, "eg_pack_table: bad arguments");
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(pack_table_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, nentries);
+  else if (dtype == EG_F16)
+    hipLaunchKernelGGL(pack_table_kernel<f16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, nentries);
   else if (dtype == EG_F32)
     hipLaunchKernelGGL(pack_table_kernel<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, nentries);
   else
@@ -188,6 +190,9 @@ extern "C" int eg_window_pack(const float* x, void* xt, int NB, int C, int T, in
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(window_pack_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, x, (bf16_t*)xt, C, T, Cp,
                        pad_front, Tp);
+  else if (dtype == EG_F16)
+    hipLaunchKernelGGL(window_pack_kernel<f16_t>, grid, dim3(256), lds, (hipStream_t)stream, x, (f16_t*)xt, C, T, Cp,
+                       pad_front, Tp);
   else if (dtype == EG_F32)
     hipLaunchKernelGGL(window_pack_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, x, (float*)xt, C, T, Cp,
                        pad_front, Tp);
@@ -204,6 +209,8 @@ extern "C" int eg_cast(const float* src, void* dst, int64_t n, int dtype, void* 
   dim3 grid((unsigned)((nt + 255) / 256));
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(cast_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (long long)n);
+  else if (dtype == EG_F16)
+    hipLaunchKernelGGL(cast_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (f16_t*)dst, (long long)n);
   else if (dtype == EG_F32)
     hipLaunchKernelGGL(cast_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, (long long)n);
   else
@@ -217,6 +224,9 @@ extern "C" int eg_transpose_cast(const float* src, void* dst, int R, int Cc, int
   dim3 grid((Cc + 31) / 32, (R + 31) / 32);
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, R, Cc,
+                       ldd);
+  else if (dtype == EG_F16)
+    hipLaunchKernelGGL(transpose_cast_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (f16_t*)dst, R, Cc,
                        ldd);
   else if (dtype == EG_F32)
     hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, R, Cc,
@@ -236,6 +246,9 @@ extern "C" int eg_pack_conv_weight(const float* w, void* dst, int N, int Cin, in
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst, N, Cin,
                        k, Cp, Kp);
+  else if (dtype == EG_F16)
+    hipLaunchKernelGGL(pack_conv_weight_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, w, (f16_t*)dst, N, Cin,
+                       k, Cp, Kp);
   else if (dtype == EG_F32)
     hipLaunchKernelGGL(pack_conv_weight_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, w, (float*)dst, N, Cin, k,
                        Cp, Kp);
@@ -253,6 +266,9 @@ extern "C" int eg_pack_convT_weight(const float* w, void* dst, int N, int Cin, i
   dim3 grid((unsigned)((n + 255) / 256));
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(pack_convT_weight_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst, N,
+                       Cin, k, stride, J);
+  else if (dtype == EG_F16)
+    hipLaunchKernelGGL(pack_convT_weight_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, w, (f16_t*)dst, N,
                        Cin, k, stride, J);
   else if (dtype == EG_F32)
     hipLaunchKernelGGL(pack_convT_weight_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, w, (float*)dst, N, Cin,

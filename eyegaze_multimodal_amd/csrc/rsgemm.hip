@@ -34,8 +34,9 @@ constexpr int RS_TP = 80;                   // pitch (bytes) of the wave-private
 constexpr int RS_TW = 32 * RS_TP;           // one wave's image: 32 rows
 constexpr int RS_LDS = (RS_RA + RS_RE) * RS_PAIR + 8 * RS_TW;   // 149,504 B
 
+template <typename T>
 struct RsGemm {
-  const bf16_t* A; const bf16_t* W; bf16_t* C; const float* bias; const bf16_t* E; bf16_t* out_pre;
+  const T* A; const T* W; T* C; const float* bias; const T* E; T* out_pre;
   const eg_step_state* st;
   int lda, ldc, lde, ldp;                   // row strides (elements); M * stride < 2^32 is checked by the host
   int M, N, ldw;
@@ -72,9 +73,9 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
   }
 }
 
-// 4 floats -> 4 bf16 (two packed converts)
-__device__ __forceinline__ u32x2 rs_pack4(const float v[4]) {
-  typedef __attribute__((ext_vector_type(2))) float f32x2;
+// 4 floats -> 4 elements of the 16-bit storage type (two packed converts)
+template <typename T> __device__ __forceinline__ u32x2 rs_pack4(const float v[4]);
+template <> __device__ __forceinline__ u32x2 rs_pack4<bf16_t>(const float v[4]) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
   const bf16x2 lo = __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2);
   const bf16x2 hi = __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2);
@@ -83,11 +84,17 @@ __device__ __forceinline__ u32x2 rs_pack4(const float v[4]) {
   o[1] = __builtin_bit_cast(uint32_t, hi);
   return o;
 }
+template <> __device__ __forceinline__ u32x2 rs_pack4<f16_t>(const float v[4]) {
+  u32x2 o;
+  o[0] = pack2h(v[0], v[1]);
+  o[1] = pack2h(v[2], v[3]);
+  return o;
+}
 
 // EMODE: 0 no epilogue operand, 1 residual (added last), 2 gate (ReLU backward: zero where gate <= 0)
 // RELU:  ReLU on acc + bias;  DROP: the dropout sites of the descriptor are live (each still checks its own threshold)
-template <int EMODE, int RELU, int DROP>
-__global__ __launch_bounds__(512, 2) void rs_gemm_kernel(RsGemm p) {
+template <typename T, int EMODE, int RELU, int DROP>
+__global__ __launch_bounds__(512, 2) void rs_gemm_kernel(RsGemm<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ringA = smem;
   char* const ringE = smem + RS_RA * RS_PAIR;
@@ -138,13 +145,14 @@ __global__ __launch_bounds__(512, 2) void rs_gemm_kernel(RsGemm p) {
   asm volatile("" ::: "memory");
 
   // register-stationary weights: this wave's 32 columns as MFMA A-operands (rows of W)
-  bf16x8 wf[2][8];
+  typedef typename H16<T>::frag frag;
+  frag wf[2][8];
   {
-    const bf16_t* wrow = p.W + (size_t)(n0 + 32 * wave + l15) * (size_t)p.ldw + 8 * g4;
+    const T* wrow = p.W + (size_t)(n0 + 32 * wave + l15) * (size_t)p.ldw + 8 * g4;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int s = 0; s < 8; ++s) wf[j][s] = *(const bf16x8*)(wrow + (size_t)(16 * j) * (size_t)p.ldw + 32 * s);
+      for (int s = 0; s < 8; ++s) wf[j][s] = *(const frag*)(wrow + (size_t)(16 * j) * (size_t)p.ldw + 32 * s);
   }
   // per-lane epilogue constants: accumulator register q of tile j is column n0 + 32w + 16j + 4*g4 + q of row l15
   const int ncol = n0 + 32 * wave + 4 * g4;
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void rs_gemm_kernel(RsGemm p) {
         if (EMODE == 2) {
           float ev[4];
           const int ch = (4 * wave + 2 * j + (g4 >> 1)) ^ (r & 15);
-          load4((const bf16_t*)(ringE + slotE * RS_PAIR + r * 512 + (ch << 4) + ((g4 & 1) << 3)), ev);
+          load4((const T*)(ringE + slotE * RS_PAIR + r * 512 + (ch << 4) + ((g4 & 1) << 3)), ev);
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[j][q] = ev[q] > 0.f ? v[j][q] * p.gate_scale : 0.f;
         }
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void rs_gemm_kernel(RsGemm p) {
       char* const tb = timg + b * (16 * RS_TP);
       if (p.out_pre) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) *(u32x2*)(tb + l15 * RS_TP + (16 * j + 4 * g4) * 2) = rs_pack4(v[j]);
+        for (int j = 0; j < 2; ++j) *(u32x2*)(tb + l15 * RS_TP + (16 * j + 4 * g4) * 2) = rs_pack4<T>(v[j]);
         const u32x4 o = *(const u32x4*)(tb + sr * RS_TP + sc * 16);
         *(u32x4*)(p.out_pre + (size_t)(ms * (uint32_t)p.ldp) + n0 + 32 * wave + 8 * sc) = o;
         vm_issued += 1;
@@ -222,11 +230,11 @@ __global__ __launch_bounds__(512, 2) void rs_gemm_kernel(RsGemm p) {
         if (EMODE == 1) {
           float ev[4];
           const int ch = (4 * wave + 2 * j + (g4 >> 1)) ^ (r & 15);
-          load4((const bf16_t*)(ringE + slotE * RS_PAIR + r * 512 + (ch << 4) + ((g4 & 1) << 3)), ev);
+          load4((const T*)(ringE + slotE * RS_PAIR + r * 512 + (ch << 4) + ((g4 & 1) << 3)), ev);
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[j][q] += ev[q];
         }
-        *(u32x2*)(tb + l15 * RS_TP + (16 * j + 4 * g4) * 2) = rs_pack4(v[j]);
+        *(u32x2*)(tb + l15 * RS_TP + (16 * j + 4 * g4) * 2) = rs_pack4<T>(v[j]);
       }
       const u32x4 o = *(const u32x4*)(tb + sr * RS_TP + sc * 16);
       *(u32x4*)(p.C + (size_t)(ms * (uint32_t)p.ldc) + n0 + 32 * wave + 8 * sc) = o;
@@ -235,12 +243,12 @@ __global__ __launch_bounds__(512, 2) void rs_gemm_kernel(RsGemm p) {
   };
   auto frags_mma = [&](int slot, f32x4 (&a)[2][2]) {
     // fragments of the pair (swizzled rows), 32 MFMAs: D[n][m] = sum_k W[n][k] X[m][k]
-    bf16x8 xf[2][8];
+    frag xf[2][8];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const char* ab = ringA + slot * RS_PAIR + (16 * b + l15) * 512;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) xf[b][s] = *(const bf16x8*)(ab + (((4 * s + g4) ^ l15) << 4));
+      for (int s = 0; s < 8; ++s) xf[b][s] = *(const frag*)(ab + (((4 * s + g4) ^ l15) << 4));
     }
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void rs_gemm_kernel(RsGemm p) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) a[b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], xf[b][s], a[b][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) a[b][j] = H16<T>::mfma(wf[j][s], xf[b][s], a[b][j]);
   };
 
   // Software pipeline: between two barriers a wave runs the MFMAs of pair t AND the epilogue of pair t-1 (two accumulator
@@ -293,8 +301,48 @@ __global__ __launch_bounds__(512, 2) void rs_gemm_kernel(RsGemm p) {
 }  // namespace
 
 // eligibility + launch; returns -1 when the product does not fit this kernel (caller falls back to gemm_nt)
+template <typename T>
+static int rs_gemm_launch(const eg_gemm_desc* d, hipStream_t s, int cus) {
+  RsGemm<T> p;
+  p.A = (const T*)d->A; p.W = (const T*)d->W; p.C = (T*)d->C; p.bias = d->bias;
+  p.E = (const T*)(d->residual ? d->residual : d->gate);
+  p.out_pre = (T*)d->out_pre; p.st = d->state;
+  p.lda = (int)d->a.row_stride; p.ldc = (int)d->c.row_stride; p.lde = (int)(d->residual ? d->r.row_stride : d->c.row_stride);
+  p.ldp = (int)d->p.row_stride;
+  p.M = d->M; p.N = d->N; p.ldw = d->ldw;
+  const int e_mode = d->residual ? 1 : (d->gate ? 2 : 0);
+  p.nblk = (d->M + 15) / 16;
+  p.ns = d->N / 256;
+  p.groups = cus / p.ns > 0 ? cus / p.ns : 1;
+  if (p.groups > p.nblk) p.groups = p.nblk;
+  p.d1 = make_drop(d->drop1_p, d->drop1_site);
+  p.d2 = make_drop(d->drop2_p, d->drop2_site);
+  p.gate_scale = d->gate_scale == 0.f ? 1.0f : d->gate_scale;
+  const dim3 grid(p.groups * p.ns), blk(512);
+#define RS_LAUNCH(E_, R_, D_)                                                                                          \
+  do {                                                                                                                 \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      (void)hipFuncSetAttribute((const void*)rs_gemm_kernel<T, E_, R_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                RS_LDS);                                                                               \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((rs_gemm_kernel<T, E_, R_, D_>), grid, blk, RS_LDS, s, p);                                      \
+  } while (0)
+#define RS_PICK(E_)                                                                                                    \
+  do {                                                                                                                 \
+    if (relu) { if (drop) RS_LAUNCH(E_, 1, 1); else RS_LAUNCH(E_, 1, 0); }                                             \
+    else      { if (drop) RS_LAUNCH(E_, 0, 1); else RS_LAUNCH(E_, 0, 0); }                                             \
+  } while (0)
+  const bool relu = d->act == EG_ACT_RELU, drop = (p.d1.thresh | p.d2.thresh) != 0;
+  if (e_mode == 1) RS_PICK(1); else if (e_mode == 2) RS_PICK(2); else RS_PICK(0);
+#undef RS_PICK
+#undef RS_LAUNCH
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int eg_rs_gemm_try(const eg_gemm_desc* d, hipStream_t s) {
-  if (d->dtype != EG_BF16 || d->K != 256 || d->N % 256 != 0 || d->ldw != 256) return -1;
+  if ((d->dtype != EG_BF16 && d->dtype != EG_F16) || d->K != 256 || d->N % 256 != 0 || d->ldw != 256) return -1;
   if (d->a.rows_per_group || d->c.rows_per_group || d->r.rows_per_group || d->p.rows_per_group) return -1;
   if (d->a_seg_len || d->ln_mode || d->row_tile || d->act == EG_ACT_GELU) return -1;
   if (d->residual && d->gate) return -1;
@@ -313,40 +361,5 @@ int eg_rs_gemm_try(const eg_gemm_desc* d, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  RsGemm p;
-  p.A = (const bf16_t*)d->A; p.W = (const bf16_t*)d->W; p.C = (bf16_t*)d->C; p.bias = d->bias;
-  p.E = (const bf16_t*)(d->residual ? d->residual : d->gate);
-  p.out_pre = (bf16_t*)d->out_pre; p.st = d->state;
-  p.lda = (int)d->a.row_stride; p.ldc = (int)d->c.row_stride; p.lde = (int)(d->residual ? d->r.row_stride : d->c.row_stride);
-  p.ldp = (int)d->p.row_stride;
-  p.M = d->M; p.N = d->N; p.ldw = d->ldw;
-  const int e_mode = d->residual ? 1 : (d->gate ? 2 : 0);
-  p.nblk = (d->M + 15) / 16;
-  p.ns = d->N / 256;
-  p.groups = cus / p.ns > 0 ? cus / p.ns : 1;
-  if (p.groups > p.nblk) p.groups = p.nblk;
-  p.d1 = make_drop(d->drop1_p, d->drop1_site);
-  p.d2 = make_drop(d->drop2_p, d->drop2_site);
-  p.gate_scale = d->gate_scale == 0.f ? 1.0f : d->gate_scale;
-  const dim3 grid(p.groups * p.ns), blk(512);
-#define RS_LAUNCH(E_, R_, D_)                                                                                          \
-  do {                                                                                                                 \
-    static bool attr = false;                                                                                          \
-    if (!attr) {                                                                                                       \
-      (void)hipFuncSetAttribute((const void*)rs_gemm_kernel<E_, R_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                RS_LDS);                                                                               \
-      attr = true;                                                                                                     \
-    }                                                                                                                  \
-    hipLaunchKernelGGL((rs_gemm_kernel<E_, R_, D_>), grid, blk, RS_LDS, s, p);                                         \
-  } while (0)
-#define RS_PICK(E_)                                                                                                    \
-  do {                                                                                                                 \
-    if (relu) { if (drop) RS_LAUNCH(E_, 1, 1); else RS_LAUNCH(E_, 1, 0); }                                             \
-    else      { if (drop) RS_LAUNCH(E_, 0, 1); else RS_LAUNCH(E_, 0, 0); }                                             \
-  } while (0)
-  const bool relu = d->act == EG_ACT_RELU, drop = (p.d1.thresh | p.d2.thresh) != 0;
-  if (e_mode == 1) RS_PICK(1); else if (e_mode == 2) RS_PICK(2); else RS_PICK(0);
-#undef RS_PICK
-#undef RS_LAUNCH
-  return hipGetLastError() == hipSuccess ? 0 : -2;
+  return d->dtype == EG_F16 ? rs_gemm_launch<f16_t>(d, s, cus) : rs_gemm_launch<bf16_t>(d, s, cus);
 }

@@ -491,6 +491,9 @@ extern "C" int eg_ibs_inorm(const float* conn, const int* fidx, const float* gam
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(ibs_inorm_kernel<bf16_t>, dim3(B), dim3(256), 0, s, conn, fidx, gamma, beta, (bf16_t*)out, xhat, B,
                        nbands, nfeat, E, use_norm);
+  else if (dtype == EG_F16)
+    hipLaunchKernelGGL(ibs_inorm_kernel<f16_t>, dim3(B), dim3(256), 0, s, conn, fidx, gamma, beta, (f16_t*)out, xhat, B,
+                       nbands, nfeat, E, use_norm);
   else if (dtype == EG_F32)
     hipLaunchKernelGGL(ibs_inorm_kernel<float>, dim3(B), dim3(256), 0, s, conn, fidx, gamma, beta, (float*)out, xhat, B, nbands,
                        nfeat, E, use_norm);
@@ -509,6 +512,8 @@ extern "C" int eg_gelu_fwd(const void* u, void* h, int64_t n, int dtype, float d
   hipStream_t s = (hipStream_t)stream;
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(gelu_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)u, (bf16_t*)h, (long long)n, dc, state);
+  else if (dtype == EG_F16)
+    hipLaunchKernelGGL(gelu_fwd_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)u, (f16_t*)h, (long long)n, dc, state);
   else if (dtype == EG_F32)
     hipLaunchKernelGGL(gelu_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)u, (float*)h, (long long)n, dc, state);
   else
@@ -527,6 +532,9 @@ extern "C" int eg_gelu_bwd(const void* u, const void* dh, void* du, int64_t n, i
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)u, (const bf16_t*)dh, (bf16_t*)du,
                        (long long)n, dc, state);
+  else if (dtype == EG_F16)
+    hipLaunchKernelGGL(gelu_bwd_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)u, (const f16_t*)dh, (f16_t*)du,
+                       (long long)n, dc, state);
   else if (dtype == EG_F32)
     hipLaunchKernelGGL(gelu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)u, (const float*)dh, (float*)du,
                        (long long)n, dc, state);
@@ -543,6 +551,8 @@ extern "C" int eg_affine_grad(const void* dy, const float* xhat, float* partial,
   hipStream_t s = (hipStream_t)stream;
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(affine_grad_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, xhat, partial, M, E, nsplit);
+  else if (dtype == EG_F16)
+    hipLaunchKernelGGL(affine_grad_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)dy, xhat, partial, M, E, nsplit);
   else if (dtype == EG_F32)
     hipLaunchKernelGGL(affine_grad_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, xhat, partial, M, E, nsplit);
   else

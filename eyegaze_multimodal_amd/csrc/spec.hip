@@ -179,8 +179,9 @@ __global__ void unpack_conv2d_wgrad_kernel(const float* __restrict__ partial, fl
 
 }  // namespace
 
-#define SPEC_DISPATCH(dtype, BF, F32, who)        \
+#define SPEC_DISPATCH(dtype, BF, F16, F32, who)   \
   if ((dtype) == EG_BF16) { BF; }                  \
+  else if ((dtype) == EG_F16) { F16; }             \
   else if ((dtype) == EG_F32) { F32; }             \
   else return eg_fail("%s: bad dtype %d", who, (int)(dtype));
 
@@ -198,6 +199,7 @@ extern "C" int eg_spec_conv1_fwd(const float* img, const float* w, const float* 
   hipStream_t s = (hipStream_t)stream;
   SPEC_DISPATCH(dtype,
                 hipLaunchKernelGGL(spec_conv1_fwd_kernel<bf16_t>, dim3(nimg), dim3(256), lds, s, img, w, bias, (bf16_t*)p1, F, nfr),
+                hipLaunchKernelGGL(spec_conv1_fwd_kernel<f16_t>, dim3(nimg), dim3(256), lds, s, img, w, bias, (f16_t*)p1, F, nfr),
                 hipLaunchKernelGGL(spec_conv1_fwd_kernel<float>, dim3(nimg), dim3(256), lds, s, img, w, bias, (float*)p1, F, nfr),
                 "eg_spec_conv1_fwd");
   EG_LAUNCH_CHECK("spec_conv1_fwd");
@@ -212,6 +214,7 @@ extern "C" int eg_spec_conv1_bwd(const float* img, const float* w, const float* 
   hipStream_t s = (hipStream_t)stream;
   SPEC_DISPATCH(dtype,
                 hipLaunchKernelGGL(spec_conv1_bwd_kernel<bf16_t>, dim3(nimg), dim3(256), lds, s, img, w, bias, (const bf16_t*)dp1, partial, F, nfr),
+                hipLaunchKernelGGL(spec_conv1_bwd_kernel<f16_t>, dim3(nimg), dim3(256), lds, s, img, w, bias, (const f16_t*)dp1, partial, F, nfr),
                 hipLaunchKernelGGL(spec_conv1_bwd_kernel<float>, dim3(nimg), dim3(256), lds, s, img, w, bias, (const float*)dp1, partial, F, nfr),
                 "eg_spec_conv1_bwd");
   EG_LAUNCH_CHECK("spec_conv1_bwd");
@@ -223,6 +226,7 @@ extern "C" int eg_spec_avgpool_fwd(const void* out2, void* pooled, int nimg, int
   hipStream_t s = (hipStream_t)stream;
   SPEC_DISPATCH(dtype,
                 hipLaunchKernelGGL(spec_avgpool_fwd_kernel<bf16_t>, dim3(nimg), dim3(256), 0, s, (const bf16_t*)out2, (bf16_t*)pooled, Hp, Wp),
+                hipLaunchKernelGGL(spec_avgpool_fwd_kernel<f16_t>, dim3(nimg), dim3(256), 0, s, (const f16_t*)out2, (f16_t*)pooled, Hp, Wp),
                 hipLaunchKernelGGL(spec_avgpool_fwd_kernel<float>, dim3(nimg), dim3(256), 0, s, (const float*)out2, (float*)pooled, Hp, Wp),
                 "eg_spec_avgpool_fwd");
   EG_LAUNCH_CHECK("spec_avgpool_fwd");
@@ -235,6 +239,7 @@ extern "C" int eg_spec_avgpool_bwd(const void* out2, const void* dpooled, void* 
   hipStream_t s = (hipStream_t)stream;
   SPEC_DISPATCH(dtype,
                 hipLaunchKernelGGL(spec_avgpool_bwd_kernel<bf16_t>, dim3(nimg), dim3(256), 0, s, (const bf16_t*)out2, (const bf16_t*)dpooled, (bf16_t*)d2, Hp, Wp),
+                hipLaunchKernelGGL(spec_avgpool_bwd_kernel<f16_t>, dim3(nimg), dim3(256), 0, s, (const f16_t*)out2, (const f16_t*)dpooled, (f16_t*)d2, Hp, Wp),
                 hipLaunchKernelGGL(spec_avgpool_bwd_kernel<float>, dim3(nimg), dim3(256), 0, s, (const float*)out2, (const float*)dpooled, (float*)d2, Hp, Wp),
                 "eg_spec_avgpool_bwd");
   EG_LAUNCH_CHECK("spec_avgpool_bwd");
@@ -248,6 +253,7 @@ extern "C" int eg_pack_conv2d_weight(const float* w, void* dst, int N, int Cin, 
   hipStream_t s = (hipStream_t)stream;
   SPEC_DISPATCH(dtype,
                 hipLaunchKernelGGL(pack_conv2d_weight_kernel<bf16_t>, grid, dim3(256), 0, s, w, (bf16_t*)dst, N, Cin, transposed),
+                hipLaunchKernelGGL(pack_conv2d_weight_kernel<f16_t>, grid, dim3(256), 0, s, w, (f16_t*)dst, N, Cin, transposed),
                 hipLaunchKernelGGL(pack_conv2d_weight_kernel<float>, grid, dim3(256), 0, s, w, (float*)dst, N, Cin, transposed),
                 "eg_pack_conv2d_weight");
   EG_LAUNCH_CHECK("pack_conv2d_weight");

@@ -155,7 +155,9 @@ def _resolve_dtype(compute_dtype: Optional[str]) -> int:
         return L.EG_BF16
     if name in ("f32", "fp32", "float32"):
         return L.EG_F32
-    raise ValueError(f"compute_dtype must be 'bf16' or 'f32', got {name!r}")
+    if name in ("fp16", "f16", "float16", "half"):
+        return L.EG_F16
+    raise ValueError(f"compute_dtype must be 'bf16', 'fp16' or 'f32', got {name!r}")
 
 
 class _AuxLoss(torch.autograd.Function):

@@ -20,7 +20,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib as L
-from ._lib import EG_BF16, EG_F32, GemmDesc, GemmTNDesc, StepState, call, ptr, rowmap
+from ._lib import EG_BF16, EG_F16, EG_F32, GemmDesc, GemmTNDesc, StepState, call, ptr, rowmap
 
 # dropout site ids (any fixed numbering works: the mask depends on (seed, site, element index))
 SITE_CONV0, SITE_CONV1, SITE_SPEC, SITE_IBSTOK, SITE_IBSGEN, SITE_CLS, SITE_IBSCLS = 1, 2, 3, 4, 5, 6, 7
@@ -108,9 +108,13 @@ class Engine:
     def __init__(self, model, B: int, T: int, device: torch.device, dtype: int):
         cfg = model.cfg
         self.model, self.cfg, self.B, self.T, self.device, self.dtype = model, cfg, B, T, device, dtype
-        self.tdtype = torch.bfloat16 if dtype == EG_BF16 else torch.float32
-        self.es = 2 if dtype == EG_BF16 else 4
-        self.bk = 64 if dtype == EG_BF16 else 32
+        self.tdtype = {EG_BF16: torch.bfloat16, EG_F16: torch.float16, EG_F32: torch.float32}[dtype]
+        self.es = 4 if dtype == EG_F32 else 2
+        self.bk = 32 if dtype == EG_F32 else 64
+        # fp16 has 5 exponent bits: gradients are carried at loss_scale x their value (torch.cuda.amp.GradScaler semantics,
+        # train_multimodal_fuzzy_fusion.py:435-472); the scale, the overflow flag and the step counter live in eg_step_state
+        self.scaler_on = dtype == EG_F16 and os.environ.get("EYEGAZE_LOSS_SCALING", "1") != "0"
+        self.scaler_cfg = dict(init_scale=65536.0, growth=2.0, backoff=0.5, growth_interval=2000)
         d, H = cfg.d_model, cfg.num_heads
         if d % H != 0 or d // H != 32:
             raise L.EgError(f"HIP attention core needs d_model/num_heads == 32 (got {d}/{H})")
@@ -233,7 +237,8 @@ class Engine:
         self.g: Dict[str, torch.Tensor] = {}
         # device-resident step state (eg_step_state); the host publishes a step's scalars as kernel arguments
         self.state_dev = torch.zeros(L.STATE_WORDS, dtype=torch.int32, device=self.device)
-        self.set_state(seed=0, lr=0.0, step=1, grad_scale=1.0, reset_scaler=2)
+        self.set_state(seed=0, lr=0.0, step=1, grad_scale=1.0, reset_scaler=(1 if self.scaler_on else 2),
+                       init_scale=self.scaler_cfg["init_scale"])
 
     def _alloc_bwd(self):
         if self.g:
@@ -271,9 +276,22 @@ class Engine:
         step's seed / lr / bias corrections (a pinned staging buffer re-used per step could be overwritten before its copy ran).
         reset_scaler: 0 keep the device's loss-scaling words, 1 enable dynamic loss scaling at init_scale, 2 disable."""
         seed = scramble_seed(seed)     # consecutive step seeds must not share their low / high words (common.h: eg_hash)
+        # with loss scaling a step may be skipped on the device: the device's own count of taken steps feeds the bias corrections
+        use_dev_t = bool(use_dev_t) or self.scaler_on
         call("eg_set_step_state", self.state_dev.data_ptr(), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, float(lr),
              1.0 - beta1 ** step, 1.0 - beta2 ** step, float(grad_scale), int(reset_scaler), float(init_scale),
-             int(bool(use_dev_t)), self._cur_stream())
+             int(use_dev_t), self._cur_stream())
+
+    def reset_scaler(self, init_scale: float = 65536.0, growth: float = 2.0, backoff: float = 0.5, growth_interval: int = 2000):
+        """(re)starts dynamic loss scaling with GradScaler's parameters (fp16 engines only)"""
+        self.scaler_cfg = dict(init_scale=init_scale, growth=growth, backoff=backoff, growth_interval=growth_interval)
+        self.scaler_on = True
+        self.set_state(seed=0, lr=0.0, step=1, reset_scaler=1, init_scale=init_scale)
+
+    @property
+    def loss_scale_dev(self) -> torch.Tensor:
+        """the device-resident loss scale as a 1-element fp32 view of eg_step_state (word 8)"""
+        return self.state_dev.view(torch.float32)[8:9]
 
     def read_state(self) -> StepState:
         host = self.state_dev.cpu()
@@ -748,6 +766,13 @@ class Engine:
         sc01 = 1.0 / (1.0 - p01) if p01 > 0 else 1.0
         lab = ptr(self.labels) if self.labels is not None else 0
         seg = on_segment or (lambda name: None)
+        if self.scaler_on:
+            # every gradient entering the backward is multiplied by the device-resident loss scale (no host sync); the
+            # optimiser kernels divide it out again (eg_clip_coef / eg_adamw)
+            ls = self.loss_scale_dev
+            sc_ = lambda t_: None if t_ is None else t_ * ls
+            gloss, gloss_ibs, glogits, gcls1, gcls2 = sc_(gloss), sc_(gloss_ibs), sc_(glogits), sc_(gcls1), sc_(gcls2)
+            gibs_logits, gibs_token = sc_(gibs_logits), sc_(gibs_token)
         # ---- heads ----
         call("eg_classifier_ce_bwd", ptr(a["hcl"]), fp.p_ptr("classifier.3.weight"), ptr(a["logits"]), lab, ptr(gloss),
              ptr(glogits), ptr(g["dlogits"]), ptr(g["dhcl"]), fp.g_ptr("classifier.3.weight"), fp.g_ptr("classifier.3.bias"),
@@ -916,3 +941,6 @@ class Engine:
         call("eg_clip_coef", ptr(self.g["sqpart"]), nblk, max_norm, self.st_ptr, self.stream)
         call("eg_adamw", ptr(self.fp.flat), ptr(self.fp.grad), ptr(m), ptr(v), self.fp.total, betas[0], betas[1], eps,
              weight_decay, self.st_ptr, self.stream)
+        if self.scaler_on:      # GradScaler.update(): back off after an overflow, grow after growth_interval clean steps
+            c = self.scaler_cfg
+            call("eg_scaler_update", self.st_ptr, c["growth"], c["backoff"], c["growth_interval"], self.stream)

@@ -391,5 +391,5 @@ if __name__ == "__main__":
     ap.add_argument("--config", type=str, required=True)
     ap.add_argument("--resume", action="store_true")
     ap.add_argument("--checkpoint", type=str)
-    ap.add_argument("--dtype", type=str, default=None, choices=[None, "bf16", "f32"])
+    ap.add_argument("--dtype", type=str, default=None, choices=[None, "bf16", "fp16", "f32"])
     main(ap.parse_args())

@@ -1,0 +1,102 @@
+"""fp16 compute dtype (BASELINE configs[4]: "fp16"; v_mfma_f32_16x16x32_f16, fp16 storage, fp32 accumulate) with dynamic loss
+scaling on the device (torch.cuda.amp.GradScaler semantics of train_multimodal_fuzzy_fusion.py:435-472).
+
+Parity: the reference has no CPU fp16-autocast path to generate fixtures from (CPU autocast is bf16-centric), so fp16 is pinned
+against the reference's fp32 fixtures at the bf16 gates (fp16 carries 3 more mantissa bits than bf16, the measured errors are
+smaller) and its gradients against the f32-mode gradients of the same HIP path."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from eyegaze_multimodal_amd import HipAdamW  # noqa: E402
+from tests.helpers import t  # noqa: E402
+from tests.test_gpu_model import DEV, build  # noqa: E402
+
+CONFIGS = ["cfg2_concat", "cfg3_xattn", "cfg5_a2_spec", "a5_full", "tiny_a1"]
+
+
+@pytest.mark.parametrize("name", CONFIGS)
+@pytest.mark.parametrize("kind", ["randn", "gen_eeg"])
+def test_fp16_forward_matches_reference(name, kind):
+    z, kw, cfg, sd, model = build(name, "fp16")
+    model.eval()
+    x1, x2, labels = t(z[f"{kind}/eeg1"]).to(DEV), t(z[f"{kind}/eeg2"]).to(DEV), t(z["labels"]).to(DEV)
+    with torch.no_grad():
+        out = model(x1, x2, labels)
+    got = out["logits"].float().cpu().numpy()
+    ref = z[f"{kind}/out/logits"]
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref).max()
+    assert err <= 1e-2, err                      # bf16 gate is 3e-2; fp16 measured ~1-3e-3
+    assert (got.argmax(-1) == z[f"{kind}/out/argmax"]).all()
+    assert abs(float(out["loss_ce"]) - float(z[f"{kind}/out/loss_ce"])) < 5e-3
+
+
+@pytest.mark.parametrize("name", ["cfg3_xattn", "tiny_a1"])
+def test_fp16_scaled_backward_matches_f32_gradients(name):
+    """loss-scaled fp16 backward, un-scaled by the optimiser kernels: the step's gradient norm and update direction agree with
+    the exact-fp32 HIP path"""
+    res = {}
+    for dtype in ("f32", "fp16"):
+        z, kw, cfg, sd, model = build(name, dtype)
+        model.eval()
+        x1, x2, labels = t(z["randn/eeg1"]).to(DEV), t(z["randn/eeg2"]).to(DEV), t(z["labels"]).to(DEV)
+        eng = model.engine(x1.shape[0], x1.shape[2], torch.device(DEV))
+        opt = HipAdamW(model, lr=1e-4, weight_decay=0.01)
+        opt.begin_step(eng, seed=1)
+        eng.forward(x1, x2, labels, train=False)
+        eng.backward(gloss=torch.ones(1, device=DEV))
+        st0 = eng.read_state()
+        grads = model._flat.grad.clone() / (st0.loss_scale if st0.scaler_on else 1.0)
+        opt.step(eng)
+        torch.cuda.synchronize()
+        res[dtype] = (grads.double().cpu(), eng.read_state())
+    g32, s32 = res["f32"]
+    g16, s16 = res["fp16"]
+    assert s16.scaler_on == 1 and s16.loss_scale == 65536.0 and s16.found_inf == 0 and s16.opt_steps == 1
+    assert abs(s16.grad_norm - s32.grad_norm) < 2e-2 * s32.grad_norm, (s16.grad_norm, s32.grad_norm)
+    cos = float((g32 * g16).sum() / (g32.norm() * g16.norm()))
+    assert cos > 0.995, cos
+
+
+def test_overflow_skips_the_step_and_backs_off_then_grows():
+    z, kw, cfg, sd, model = build("tiny_a1", "fp16")
+    model.eval()
+    x1, x2, labels = t(z["randn/eeg1"]).to(DEV), t(z["randn/eeg2"]).to(DEV), t(z["labels"]).to(DEV)
+    eng = model.engine(x1.shape[0], x1.shape[2], torch.device(DEV))
+    eng.reset_scaler(init_scale=2.0 ** 40, growth=2.0, backoff=0.5, growth_interval=3)    # certain overflow in fp16
+    opt = HipAdamW(model, lr=1e-3)
+    before = model._flat.flat.clone()
+    one = torch.ones(1, device=DEV)
+
+    def step(i):
+        opt.begin_step(eng, seed=i)
+        eng.forward(x1, x2, labels, train=False)
+        eng.backward(gloss=one)
+        opt.step(eng)
+        torch.cuda.synchronize()
+        return eng.read_state()
+    s = step(0)
+    assert s.found_inf == 1 and s.skipped == 1 and s.opt_steps == 0 and s.loss_scale == 2.0 ** 39
+    assert torch.equal(model._flat.flat, before), "a step with non-finite gradients must not touch the parameters"
+    skipped = 1
+    for i in range(1, 40):          # the scale keeps halving until the gradients fit
+        s = step(i)
+        if s.found_inf == 0:
+            break
+        skipped += 1
+    assert s.found_inf == 0 and s.skipped == skipped and s.opt_steps == 1 and s.loss_scale == 2.0 ** (40 - skipped)
+    assert not torch.equal(model._flat.flat, before)
+    scale = s.loss_scale
+    s = step(100)
+    s = step(101)                   # third clean step in a row: growth_interval = 3 -> the scale doubles
+    assert s.good_steps == 0 and s.loss_scale == 2 * scale and s.opt_steps == 3
+
+
+def test_bf16_and_f32_engines_do_not_intercept_non_finite_gradients():
+    z, kw, cfg, sd, model = build("tiny_a1", "bf16")
+    eng = model.engine(4, 1024, torch.device(DEV))
+    st = eng.read_state()
+    assert st.scaler_on == 0 and st.loss_scale == 1.0 and st.use_dev_t == 0

@@ -1,10 +1,12 @@
 """GPU parity tests, model level: the HIP DualEEGTransformer against the golden fixtures emitted by the
 reference (tests/golden, see oracle/make_golden.py) and against the CPU oracle on fresh seeded inputs.
 
-Tolerances (SURVEY.md §8c evidence: reference fp32 vs fp64 differs by ~2e-7 on logits):
-  bf16 compute (bf16 storage, fp32 accumulate):  |dlogit| <= 3e-2, argmax equal wherever the reference's
-      top-2 margin exceeds 6e-2 (all fixture samples do); stage tensors rtol 3e-2 of their max-abs.
-  f32 compute (exact-fp32 MFMA, where a kernel exists): |dlogit| <= 1e-4.
+Tolerances = at most 2x the errors MEASURED on the MI355X (profiles/r02_parity_table.json, written by tests/parity_table.py;
+SURVEY.md 8c evidence: reference fp32 vs fp64 differs by ~2e-7 on logits):
+  bf16 compute (bf16 storage, fp32 accumulate):  measured max |dlogit| 1.74e-2 over all fixtures -> gate 3e-2; argmax equal
+      wherever the reference's top-2 margin exceeds 4e-2; stage tensors rtol 3e-2 of their max-abs.
+  f32 compute (exact-fp32 MFMA): measured max |dlogit| 1.8e-6 -> gate 4e-6 (SURVEY 8c proposed 1e-5), argmax on every sample;
+      configurations with synchrony tokens 5e-5 (sign()-based PLI / wPLI: 2.2e-5 measured on the 512-sample fixture).
 """
 import numpy as np
 import pytest
@@ -78,7 +80,7 @@ def test_eval_forward_matches_reference(name, kind):
     err = np.abs(got - ref_logits).max()
     assert err <= 3e-2, f"logits err {err}"
     top2 = np.sort(ref_logits, -1)
-    decided = (top2[:, -1] - top2[:, -2]) > 6e-2
+    decided = (top2[:, -1] - top2[:, -2]) > 4e-2
     assert (got.argmax(-1)[decided] == z[f"{kind}/out/argmax"][decided]).all()
     assert abs(float(out["loss_ce"]) - float(z[f"{kind}/out/loss_ce"])) < 2e-2
     for k in ("cls1", "cls2", "ibs_token"):
@@ -102,10 +104,11 @@ def test_eval_forward_matches_reference(name, kind):
 @pytest.mark.parametrize("name", ALL)
 @pytest.mark.parametrize("kind", ["randn", "gen_eeg"])
 def test_f32_forward_and_gradients_are_tight(name, kind):
-    """compute_dtype='f32' (exact-fp32 MFMA + fmaf attention): logits within 1e-4 of the reference's fp32 CPU
-    result, argmax bit-exact on every sample, every parameter gradient within 1e-3 relative (Frobenius).
-    Configurations with synchrony tokens get 2e-3 / 2e-2: the sign()-based PLI / wPLI features are discontinuous
-    (one flipped sample of T=1024 moves an entry by 2e-3) and the radix-2 LDS FFT rounds differently from pocketfft."""
+    """compute_dtype='f32' (exact-fp32 MFMA + fmaf attention): logits within 4e-6 of the reference's fp32 CPU
+    result (measured 1.8e-6), argmax bit-exact on every sample, every parameter gradient within 1e-3 relative (Frobenius;
+    measured 6.6e-4).  Configurations with synchrony tokens get 5e-5 / 2e-2: the sign()-based PLI / wPLI features are
+    discontinuous (one flipped sample of T=1024 moves an entry by 2e-3; 2.2e-5 on logits over 512 samples, gradient of the
+    tokenizer's instance-norm gain 1.45e-2) and the radix-2 LDS FFT rounds differently from pocketfft."""
     z, kw, cfg, sd, model = build(name, "f32")
     model.eval()
     x1, x2, labels = t(z[f"{kind}/eeg1"]).to(DEV), t(z[f"{kind}/eeg2"]).to(DEV), t(z["labels"]).to(DEV)
@@ -114,7 +117,7 @@ def test_f32_forward_and_gradients_are_tight(name, kind):
     loss.backward()
     torch.cuda.synchronize()
     ibs = cfg.use_ibs
-    ltol, gtol = (2e-3, 2e-2) if ibs else ((3e-4, 2e-3) if cfg.use_spectrogram else (1e-4, 1e-3))
+    ltol, gtol = (5e-5, 2e-2) if ibs else ((4e-6, 1e-3) if cfg.use_spectrogram else (4e-6, 1e-3))
     got = out["logits"].detach().cpu().numpy()
     assert np.abs(got - z[f"{kind}/out/logits"]).max() <= ltol
     assert (got.argmax(-1) == z[f"{kind}/out/argmax"]).all()
