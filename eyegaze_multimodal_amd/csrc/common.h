@@ -108,7 +108,8 @@ __device__ __forceinline__ void load8(const f16_t* p, float v[8]) {
   u32x4 a = *(const u32x4*)p;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const f32x2 t = __builtin_convertvector(__builtin_bit_cast(f16x2, a[i]), f32x2);
+    const uint32_t w = a[i];     // (a bit_cast applied directly to a vector element reads element 0 of the vector)
+    const f32x2 t = __builtin_convertvector(__builtin_bit_cast(f16x2, w), f32x2);
     v[2 * i] = t[0];
     v[2 * i + 1] = t[1];
   }
@@ -123,7 +124,8 @@ __device__ __forceinline__ void load4(const f16_t* p, float v[4]) {
   u32x2 a = *(const u32x2*)p;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const f32x2 t = __builtin_convertvector(__builtin_bit_cast(f16x2, a[i]), f32x2);
+    const uint32_t w = a[i];
+    const f32x2 t = __builtin_convertvector(__builtin_bit_cast(f16x2, w), f32x2);
     v[2 * i] = t[0];
     v[2 * i + 1] = t[1];
   }

@@ -14,7 +14,7 @@ from eyegaze_multimodal_amd import _lib as L  # noqa: E402
 from eyegaze_multimodal_amd._lib import GemmDesc, GemmTNDesc, StepState, call, ptr, rowmap  # noqa: E402
 
 DEV = "cuda"
-DT = {L.EG_BF16: torch.bfloat16, L.EG_F32: torch.float32}
+DT = {L.EG_BF16: torch.bfloat16, L.EG_F16: torch.float16, L.EG_F32: torch.float32}
 
 
 def dev_state(seed=1234, lr=1e-4, step=1, grad_scale=1.0):
@@ -52,10 +52,10 @@ def gemm_nt(A, W, M, N, K, dtype, *, out=None, a=None, c=None, r=None, p=None, b
 
 def tol(dtype, k=1.0):
     # bf16: output rounding 2^-9 relative + fp32 accumulation; f32: accumulation order only
-    return dict(rtol=1.0e-2 * k, atol=2e-2 * k) if dtype == L.EG_BF16 else dict(rtol=2e-5 * k, atol=2e-5 * k)
+    return dict(rtol=1.0e-2 * k, atol=2e-2 * k) if dtype != L.EG_F32 else dict(rtol=2e-5 * k, atol=2e-5 * k)
 
 
-@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F32])
+@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16, L.EG_F32])
 @pytest.mark.parametrize("shape", [(300, 136, 128), (520, 768, 256), (128, 128, 64), (33, 8, 1024)])
 def test_gemm_nt_plain(dtype, shape):
     M, N, K = shape
@@ -70,7 +70,7 @@ def test_gemm_nt_plain(dtype, shape):
     torch.testing.assert_close(out.cpu().double(), ref, **tol(dtype))
 
 
-@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F32])
+@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16, L.EG_F32])
 def test_gemm_nt_asymmetric_identity(dtype):
     """A = I with an asymmetric W catches a transposed accumulator write (guide: A=I check)."""
     K = N = 128
@@ -82,7 +82,7 @@ def test_gemm_nt_asymmetric_identity(dtype):
     torch.testing.assert_close(out.cpu().float(), W.float().T.contiguous(), rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F32])
+@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16, L.EG_F32])
 def test_conv1d_as_grouped_gemm(dtype):
     """Strided Conv1d(k=25, s=4, p=12)+ReLU on channel-last padded rows == F.conv1d (D:154-171)."""
     NB, Cc, T, dm, k, s = 3, 8, 256, 64, 25, 4
@@ -91,7 +91,7 @@ def test_conv1d_as_grouped_gemm(dtype):
     x = torch.randn(NB, Cc, T, generator=g)
     w = torch.randn(dm, Cc, k, generator=g) / math.sqrt(Cc * k)
     b = torch.randn(dm, generator=g) * 0.1
-    bk = 64 if dtype == L.EG_BF16 else 32
+    bk = 64 if dtype != L.EG_F32 else 32
     K0 = (k * Cc + bk - 1) // bk * bk
     T1 = (T + 2 * pad - k) // s + 1
     Tp = max(T + 2 * pad, s * (T1 - 1) + K0 // Cc + 1)
@@ -111,7 +111,7 @@ def test_conv1d_as_grouped_gemm(dtype):
     torch.testing.assert_close(out.cpu().double(), ref, **tol(dtype))
 
 
-@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F32])
+@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16, L.EG_F32])
 def test_gemm_nt_dropout_and_gate(dtype):
     M, N, K = 256, 256, 128
     g = torch.Generator().manual_seed(9)
@@ -152,7 +152,7 @@ def test_gemm_nt_dropout_and_gate(dtype):
     torch.testing.assert_close(gg.float(), ref, rtol=1e-2, atol=1e-2)
 
 
-@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F32])
+@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16, L.EG_F32])
 @pytest.mark.parametrize("shape", [(1000, 136, 200), (520, 768, 256), (37, 8, 64), (4096, 256, 1024)])
 def test_gemm_tn(dtype, shape):
     M, N, K = shape
@@ -180,7 +180,7 @@ def test_gemm_tn(dtype, shape):
     torch.testing.assert_close(o.cpu().double(), dY.double().sum(0), rtol=1e-5, atol=1e-3)
 
 
-@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F32])
+@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16, L.EG_F32])
 @pytest.mark.parametrize("D", [256, 64])
 def test_layernorm(dtype, D):
     M = 777
@@ -226,15 +226,16 @@ def _attn_ref(qkv, NB, S, H, kv_shift, dO=None):
     return o, lse
 
 
+@pytest.mark.parametrize("dt16", [L.EG_BF16, L.EG_F16])
 @pytest.mark.parametrize("S,kv_shift", [(65, 0), (65, 3), (73, 0), (115, 3), (139, 0), (16, 0), (96, 3)])
-def test_attention_fwd_bwd(S, kv_shift):
+def test_attention_fwd_bwd(S, kv_shift, dt16):
     NB, H = 6, 4
     D = H * 32
     g = torch.Generator().manual_seed(S)
-    qkv = torch.randn(NB * S, 3 * D, generator=g).to(torch.bfloat16)
-    dO = torch.randn(NB * S, D, generator=g).to(torch.bfloat16)
-    qkvd, ctx, lse = qkv.to(DEV), torch.zeros(NB * S, D, device=DEV, dtype=torch.bfloat16), torch.zeros(NB, H, S, device=DEV)
-    call("eg_attention_fwd", ptr(qkvd), ptr(ctx), ptr(lse), NB, S, H, kv_shift, L.EG_BF16, 0.0, 0, 0, 0)
+    qkv = torch.randn(NB * S, 3 * D, generator=g).to(DT[dt16])
+    dO = torch.randn(NB * S, D, generator=g).to(DT[dt16])
+    qkvd, ctx, lse = qkv.to(DEV), torch.zeros(NB * S, D, device=DEV, dtype=DT[dt16]), torch.zeros(NB, H, S, device=DEV)
+    call("eg_attention_fwd", ptr(qkvd), ptr(ctx), ptr(lse), NB, S, H, kv_shift, dt16, 0.0, 0, 0, 0)
     torch.cuda.synchronize()
     qr = qkv.double().requires_grad_(True)
     o_ref, lse_ref = _attn_ref(qr, NB, S, H, kv_shift)
@@ -244,7 +245,7 @@ def test_attention_fwd_bwd(S, kv_shift):
     o_ref.backward(dO.double())
     dqkv = torch.zeros_like(qkvd)
     dOd = dO.to(DEV)
-    call("eg_attention_bwd", ptr(qkvd), ptr(ctx), ptr(dOd), ptr(lse), ptr(dqkv), NB, S, H, kv_shift, L.EG_BF16, 0.0, 0, 0, 0)
+    call("eg_attention_bwd", ptr(qkvd), ptr(ctx), ptr(dOd), ptr(lse), ptr(dqkv), NB, S, H, kv_shift, dt16, 0.0, 0, 0, 0)
     torch.cuda.synchronize()
     got, ref = dqkv.cpu().double(), qr.grad
     err = (got - ref).abs().max().item()
@@ -530,7 +531,7 @@ def _row_gemm(A, W, M, K, dtype, *, out, bias=None, residual=None, state=None, d
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F32])
+@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16, L.EG_F32])
 @pytest.mark.parametrize("M,K", [(520, 256), (64, 64), (1000, 1024), (130, 768)])
 def test_gemm_row_tile_matches_plain_tile(dtype, M, K):
     g = torch.Generator().manual_seed(M + K)
@@ -545,7 +546,7 @@ def test_gemm_row_tile_matches_plain_tile(dtype, M, K):
     assert float(out[M:].float().min()) == 7.0
 
 
-@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F32])
+@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16, L.EG_F32])
 @pytest.mark.parametrize("M,K", [(520, 256), (97, 1024)])
 def test_gemm_row_layernorm_forward(dtype, M, K):
     g = torch.Generator().manual_seed(M * 3 + K)
@@ -570,10 +571,10 @@ def test_gemm_row_layernorm_forward(dtype, M, K):
     y2, st2 = torch.zeros_like(y), torch.zeros_like(stats)
     call("eg_layernorm_fwd", ptr(out), ptr(gamma), ptr(beta), ptr(y2), ptr(st2), M, 256, dtype, 0)
     torch.cuda.synchronize()
-    torch.testing.assert_close(y.float().cpu(), y2.float().cpu(), rtol=0, atol=1e-2 if dtype == L.EG_BF16 else 1e-5)
+    torch.testing.assert_close(y.float().cpu(), y2.float().cpu(), rtol=0, atol=1e-2 if dtype != L.EG_F32 else 1e-5)
 
 
-@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F32])
+@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16, L.EG_F32])
 @pytest.mark.parametrize("M,K,p", [(520, 1024, 0.0), (200, 768, 0.1), (64, 256, 0.1)])
 def test_gemm_row_layernorm_backward(dtype, M, K, p):
     """dy = A W^T + residual; LayerNorm backward in the epilogue == the stand-alone kernel fed with dy, and == autograd."""
@@ -601,10 +602,10 @@ def test_gemm_row_layernorm_backward(dtype, M, K, p):
     gr = gamma.double().cpu().clone().requires_grad_(True)
     br = torch.zeros(256, dtype=torch.float64, requires_grad=True)
     torch.nn.functional.layer_norm(xr, (256,), gr, br, 1e-5).backward(dy)
-    k = 3.0 if dtype == L.EG_BF16 else 20.0       # dx sums 256 products per row
+    k = 3.0 if dtype != L.EG_F32 else 20.0       # dx sums 256 products per row
     torch.testing.assert_close(dx.cpu().double(), xr.grad, **tol(dtype, k))
-    torch.testing.assert_close(part[:, 0].sum(0).cpu().double(), gr.grad, rtol=2e-2 if dtype == L.EG_BF16 else 1e-4, atol=0.3 if dtype == L.EG_BF16 else 1e-3)
-    torch.testing.assert_close(part[:, 1].sum(0).cpu().double(), br.grad, rtol=2e-2 if dtype == L.EG_BF16 else 1e-4, atol=0.3 if dtype == L.EG_BF16 else 1e-3)
+    torch.testing.assert_close(part[:, 0].sum(0).cpu().double(), gr.grad, rtol=2e-2 if dtype != L.EG_F32 else 1e-4, atol=0.3 if dtype != L.EG_F32 else 1e-3)
+    torch.testing.assert_close(part[:, 1].sum(0).cpu().double(), br.grad, rtol=2e-2 if dtype != L.EG_F32 else 1e-4, atol=0.3 if dtype != L.EG_F32 else 1e-3)
     # the dropout-masked copy uses the same (seed, site, element) mask as the stand-alone kernel
     dx2, dxd2, part2 = torch.zeros_like(dx), torch.zeros_like(dx), torch.zeros(512, 2, 256, device=DEV)
     call("eg_layernorm_bwd", ptr(dy_out), ptr(x), ptr(stats), ptr(gamma), ptr(dx2), ptr(dxd2), ptr(part2), 512, M, 256, dtype,
