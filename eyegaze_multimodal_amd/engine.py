@@ -755,7 +755,7 @@ class Engine:
     # Gradients land in the flat gradient buffer (overwritten, not accumulated).
     # ------------------------------------------------------------------------------------------
     def backward(self, gloss=None, gloss_ibs=None, glogits=None, gcls1=None, gcls2=None, gibs_logits=None,
-                 gibs_token=None, on_segment=None):
+                 gibs_token=None, on_segment=None, prescaled: bool = False):
         self._alloc_bwd()
         cfg, d, F, H = self.cfg, self.cfg.d_model, self.cfg.d_ff, self.cfg.num_heads
         B, NB, M, S, a, w, fp, g, es = self.B, self.NB, self.M, self.S, self.a, self.w, self.fp, self.g, self.es
@@ -766,7 +766,7 @@ class Engine:
         sc01 = 1.0 / (1.0 - p01) if p01 > 0 else 1.0
         lab = ptr(self.labels) if self.labels is not None else 0
         seg = on_segment or (lambda name: None)
-        if self.scaler_on:
+        if self.scaler_on and not prescaled:
             # every gradient entering the backward is multiplied by the device-resident loss scale (no host sync); the
             # optimiser kernels divide it out again (eg_clip_coef / eg_adamw)
             ls = self.loss_scale_dev

@@ -37,21 +37,7 @@ def _alloc(model, eng: Engine):
     f32 = torch.float32
     a, w = eng.a, eng.w
     if cfg.use_spectrogram:
-        F, nfr = cfg.spec_freq_bins, 1 + T // cfg.spec_hop_length
-        Hp, Wp = F // 2, nfr // 2
-        nimg = NB * Cn
-        eng.sp = dict(F=F, nfr=nfr, Hp=Hp, Wp=Wp, nimg=nimg, rows=nimg * (Hp + 2) * Wp)
-        w["spc2"] = eng._t(64, 384)
-        w["spc2T"] = eng._t(32, 768)
-        w["spp0"] = eng._t(2 * d, 1024)
-        w["spp0T"] = eng._t(1024, 2 * d)
-        w["spp3"] = eng._t(d, 2 * d)
-        w["spp3T"] = eng._t(2 * d, d)
-        a["spimg"] = eng._t(nimg, F, nfr, dtype=f32)
-        a["sp_p1"] = eng._t(nimg * (Hp + 2) * (Wp + 4) * 32 + 4 * (Wp + 4) * 32)   # + slack rows read by the unused tail rows
-        a["sp_out2"] = eng._t(nimg * (Hp + 2) * Wp, 64)
-        a["sp_pooled"] = eng._t(nimg, 1024)
-        a["sp_hp0"] = eng._t(nimg, 2 * d)
+        spec_cnn_alloc(eng, NB * Cn, cfg.spec_freq_bins, 1 + T // cfg.spec_hop_length)
     if cfg.use_ibs:
         bands = ROBUST_BANDS if cfg.use_robust_ibs else SCALAR_BANDS
         nb, nsig = len(bands), NB * Cn
@@ -93,11 +79,7 @@ def _alloc_bwd(model, eng: Engine):
     g = eng.g
     if cfg.use_spectrogram:
         sp = eng.sp
-        g["sp_d2"] = eng._t(sp["nimg"] * (sp["Hp"] + 2) * (sp["Wp"] + 4) * 64 + 4 * (sp["Wp"] + 4) * 64)
-        g["sp_dp1"] = eng._t(sp["rows"], 32)
-        g["sp_dpooled"] = eng._t(sp["nimg"], 1024)
-        g["sp_dhp0"] = eng._t(sp["nimg"], 2 * d)
-        g["sp_part"] = eng._t(sp["nimg"], 320, dtype=torch.float32)
+        spec_cnn_alloc_bwd(eng)
     if cfg.use_ibs:
         if cfg.use_robust_ibs:
             ntok, E = cfg.num_ibs_tokens, eng.C * eng.C
@@ -120,12 +102,7 @@ def pack(model, eng: Engine):
     _alloc(model, eng)
     if cfg.use_spectrogram:
         pre = "spectrogram_generator."
-        call("eg_pack_conv2d_weight", fp.p_ptr(pre + "spec_conv.3.weight"), ptr(w["spc2"]), 64, 32, 0, dt, st)
-        call("eg_pack_conv2d_weight", fp.p_ptr(pre + "spec_conv.3.weight"), ptr(w["spc2T"]), 64, 32, 1, dt, st)
-        eng.p_cast(fp.p_ptr(pre + "proj.0.weight"), ptr(w["spp0"]), 2 * d * 1024)
-        eng.p_transpose(fp.p_ptr(pre + "proj.0.weight"), ptr(w["spp0T"]), 2 * d, 1024, 2 * d)
-        eng.p_cast(fp.p_ptr(pre + "proj.3.weight"), ptr(w["spp3"]), d * 2 * d)
-        eng.p_transpose(fp.p_ptr(pre + "proj.3.weight"), ptr(w["spp3T"]), d, 2 * d, d)
+        spec_cnn_pack(eng, pre)
     if cfg.use_ibs and cfg.use_robust_ibs:
         pre, ntok, E = "ibs_tokenizer.", cfg.num_ibs_tokens, eng.C * eng.C
         eng.p_cast(fp.p_ptr(pre + "bottleneck.0.weight"), ptr(w["ib0"]), 64 * E)
@@ -219,28 +196,98 @@ def forward(model, eng: Engine, eeg1, eeg2, train: bool):
         for i, x in enumerate((eeg1, eeg2)):
             call("eg_stft_logmag", ptr(x), ptr(win), ptr(a["spimg"]) + i * B * Cn * F * nfr * 4, B * Cn, T, cfg.spec_n_fft,
                  cfg.spec_hop_length, F, st)
-        call("eg_spec_conv1_fwd", ptr(a["spimg"]), fp.p_ptr(pre + "spec_conv.0.weight"), fp.p_ptr(pre + "spec_conv.0.bias"),
-             ptr(a["sp_p1"]), nimg, F, nfr, dt, st)
-        row = (Wp + 4) * 32
-        eng.gemm(ptr(a["sp_p1"]), ptr(w["spc2"]), ptr(a["sp_out2"]), sp["rows"], 64, 384, a=rowmap(32, row, Wp), seg=(128, row),
-                 bias=fp.p_ptr(pre + "spec_conv.3.bias"), act=L.ACT_RELU)
-        conv2 = model.spectrogram_generator.spec_conv[3]
-        if conv2._forward_hooks:
-            # Grad-CAM contract (5_Metrics/eeg_metrics.py:742-764): a forward hook on spec_conv[3] sees that layer's output
-            # (before the ReLU the production GEMM fuses), once per stream, as [B*C, 64, H', W']
-            tmp = torch.empty_like(a["sp_out2"])
-            eng.gemm(ptr(a["sp_p1"]), ptr(w["spc2"]), ptr(tmp), sp["rows"], 64, 384, a=rowmap(32, row, Wp), seg=(128, row),
-                     bias=fp.p_ptr(pre + "spec_conv.3.bias"))
-            act = tmp.view(nimg, Hp + 2, Wp, 64)[:, :Hp].permute(0, 3, 1, 2).float()
-            for half in (act[: nimg // 2], act[nimg // 2:]):
-                for hook in list(conv2._forward_hooks.values()):
-                    hook(conv2, (None,), half.contiguous())
-        call("eg_spec_avgpool_fwd", ptr(a["sp_out2"]), ptr(a["sp_pooled"]), nimg, Hp, Wp, dt, st)
-        eng.gemm(ptr(a["sp_pooled"]), ptr(w["spp0"]), ptr(a["sp_hp0"]), nimg, 2 * d, 1024, bias=fp.p_ptr(pre + "proj.0.bias"),
-                 act=L.ACT_RELU, drop1=(p01, SITE_SPEC))
         off = (1 + n_ibs) * d * es
-        eng.gemm(ptr(a["sp_hp0"]), ptr(w["spp3"]), ptr(a["x0"]) + off, nimg, d, 2 * d, c=rowmap(d, S * d, Cn), r=rowmap(d, 0, Cn),
-                 bias=fp.p_ptr(pre + "proj.3.bias"), residual=ptr(w["pos"]) + off)
+        spec_cnn_forward(eng, pre, p01, model.spectrogram_generator.spec_conv[3], ptr(a["x0"]) + off, rowmap(d, S * d, Cn),
+                         rowmap(d, 0, Cn), ptr(w["pos"]) + off)
+
+
+def spec_cnn_forward(eng, pre, p01, conv2, out_ptr, c_map, r_map, residual_ptr):
+    """The reference's 2-D CNN over one-channel images (D:70-86, D:123-130): Conv2d(1->32,3x3)+ReLU+MaxPool2 (one kernel),
+    Conv2d(32->64,3x3)+ReLU as a segmented-row GEMM, AdaptiveAvgPool(4,4), Linear(1024->2d)+ReLU+Dropout, Linear(2d->d) whose
+    epilogue writes rows addressed by c_map at out_ptr (+ residual rows r_map).  Images are eng.a["spimg"] [nimg, F, nfr] f32;
+    parameters are `pre`spec_conv.{0,3}.* / `pre`proj.{0,3}.*.  Shared by the spectrogram tokens of DualEEGTransformer and by the
+    image branch of the multimodal fusion model (image_encoder.py)."""
+    a, w, fp, dt, st, sp, d = eng.a, eng.w, eng.fp, eng.dtype, eng.stream, eng.sp, eng.cfg.d_model
+    F, nfr, Hp, Wp, nimg = sp["F"], sp["nfr"], sp["Hp"], sp["Wp"], sp["nimg"]
+    call("eg_spec_conv1_fwd", ptr(a["spimg"]), fp.p_ptr(pre + "spec_conv.0.weight"), fp.p_ptr(pre + "spec_conv.0.bias"),
+         ptr(a["sp_p1"]), nimg, F, nfr, dt, st)
+    row = (Wp + 4) * 32
+    eng.gemm(ptr(a["sp_p1"]), ptr(w["spc2"]), ptr(a["sp_out2"]), sp["rows"], 64, 384, a=rowmap(32, row, Wp), seg=(128, row),
+             bias=fp.p_ptr(pre + "spec_conv.3.bias"), act=L.ACT_RELU)
+    if conv2 is not None and conv2._forward_hooks:
+        # Grad-CAM contract (5_Metrics/eeg_metrics.py:742-764): a forward hook on spec_conv[3] sees that layer's output
+        # (before the ReLU the production GEMM fuses), once per stream, as [B*C, 64, H', W']
+        tmp = torch.empty_like(a["sp_out2"])
+        eng.gemm(ptr(a["sp_p1"]), ptr(w["spc2"]), ptr(tmp), sp["rows"], 64, 384, a=rowmap(32, row, Wp), seg=(128, row),
+                 bias=fp.p_ptr(pre + "spec_conv.3.bias"))
+        act = tmp.view(nimg, Hp + 2, Wp, 64)[:, :Hp].permute(0, 3, 1, 2).float()
+        for half in (act[: nimg // 2], act[nimg // 2:]):
+            for hook in list(conv2._forward_hooks.values()):
+                hook(conv2, (None,), half.contiguous())
+    call("eg_spec_avgpool_fwd", ptr(a["sp_out2"]), ptr(a["sp_pooled"]), nimg, Hp, Wp, dt, st)
+    eng.gemm(ptr(a["sp_pooled"]), ptr(w["spp0"]), ptr(a["sp_hp0"]), nimg, 2 * d, 1024, bias=fp.p_ptr(pre + "proj.0.bias"),
+             act=L.ACT_RELU, drop1=(p01, SITE_SPEC))
+    eng.gemm(ptr(a["sp_hp0"]), ptr(w["spp3"]), out_ptr, nimg, d, 2 * d, c=c_map, r=r_map, bias=fp.p_ptr(pre + "proj.3.bias"),
+             residual=residual_ptr)
+
+
+def spec_cnn_pack(eng, pre):
+    """compute-dtype copies of the CNN's GEMM weights (run once per optimiser step, from the fp32 masters)"""
+    fp, w, dt, st, d = eng.fp, eng.w, eng.dtype, eng.stream, eng.cfg.d_model
+    call("eg_pack_conv2d_weight", fp.p_ptr(pre + "spec_conv.3.weight"), ptr(w["spc2"]), 64, 32, 0, dt, st)
+    call("eg_pack_conv2d_weight", fp.p_ptr(pre + "spec_conv.3.weight"), ptr(w["spc2T"]), 64, 32, 1, dt, st)
+    eng.p_cast(fp.p_ptr(pre + "proj.0.weight"), ptr(w["spp0"]), 2 * d * 1024)
+    eng.p_transpose(fp.p_ptr(pre + "proj.0.weight"), ptr(w["spp0T"]), 2 * d, 1024, 2 * d)
+    eng.p_cast(fp.p_ptr(pre + "proj.3.weight"), ptr(w["spp3"]), d * 2 * d)
+    eng.p_transpose(fp.p_ptr(pre + "proj.3.weight"), ptr(w["spp3T"]), d, 2 * d, d)
+
+
+def spec_cnn_alloc(eng, nimg, F, nfr):
+    """workspaces of spec_cnn_forward / spec_cnn_backward for nimg images of F x nfr"""
+    d, f32 = eng.cfg.d_model, torch.float32
+    a, w = eng.a, eng.w
+    Hp, Wp = F // 2, nfr // 2
+    eng.sp = dict(F=F, nfr=nfr, Hp=Hp, Wp=Wp, nimg=nimg, rows=nimg * (Hp + 2) * Wp)
+    w["spc2"] = eng._t(64, 384)
+    w["spc2T"] = eng._t(32, 768)
+    w["spp0"] = eng._t(2 * d, 1024)
+    w["spp0T"] = eng._t(1024, 2 * d)
+    w["spp3"] = eng._t(d, 2 * d)
+    w["spp3T"] = eng._t(2 * d, d)
+    a["spimg"] = eng._t(nimg, F, nfr, dtype=f32)
+    a["sp_p1"] = eng._t(nimg * (Hp + 2) * (Wp + 4) * 32 + 4 * (Wp + 4) * 32)   # + slack rows read by the unused tail rows
+    a["sp_out2"] = eng._t(nimg * (Hp + 2) * Wp, 64)
+    a["sp_pooled"] = eng._t(nimg, 1024)
+    a["sp_hp0"] = eng._t(nimg, 2 * d)
+
+
+def spec_cnn_alloc_bwd(eng):
+    sp, d, g = eng.sp, eng.cfg.d_model, eng.g
+    g["sp_d2"] = eng._t(sp["nimg"] * (sp["Hp"] + 2) * (sp["Wp"] + 4) * 64 + 4 * (sp["Wp"] + 4) * 64)
+    g["sp_dp1"] = eng._t(sp["rows"], 32)
+    g["sp_dpooled"] = eng._t(sp["nimg"], 1024)
+    g["sp_dhp0"] = eng._t(sp["nimg"], 2 * d)
+    g["sp_part"] = eng._t(sp["nimg"], 320, dtype=torch.float32)
+
+
+def spec_cnn_backward(eng, pre, dy_ptr, dmap, sc01):
+    """backward of spec_cnn_forward from the gradient rows dy (addressed by dmap) of its output"""
+    a, w, g, fp, dt, st, sp, d, es = eng.a, eng.w, eng.g, eng.fp, eng.dtype, eng.stream, eng.sp, eng.cfg.d_model, eng.es
+    F, nfr, Hp, Wp, nimg, rows = sp["F"], sp["nfr"], sp["Hp"], sp["Wp"], sp["nimg"], sp["rows"]
+    eng.wgrad(dy_ptr, ptr(a["sp_hp0"]), 0, nimg, d, 2 * d, y=dmap, linear=[pre + "proj.3"])
+    eng.gemm(dy_ptr, ptr(w["spp3T"]), ptr(g["sp_dhp0"]), nimg, 2 * d, d, a=dmap, gate=ptr(a["sp_hp0"]), gate_scale=sc01)
+    eng.wgrad(ptr(g["sp_dhp0"]), ptr(a["sp_pooled"]), 0, nimg, 2 * d, 1024, linear=[pre + "proj.0"])
+    eng.gemm(ptr(g["sp_dhp0"]), ptr(w["spp0T"]), ptr(g["sp_dpooled"]), nimg, 1024, 2 * d)
+    call("eg_spec_avgpool_bwd", ptr(a["sp_out2"]), ptr(g["sp_dpooled"]), ptr(g["sp_d2"]), nimg, Hp, Wp, dt, st)
+    row32, row64 = (Wp + 4) * 32, (Wp + 4) * 64
+    eng.wgrad(ptr(g["sp_d2"]) + (row64 + 64) * es, ptr(a["sp_p1"]), fp.g_ptr(pre + "spec_conv.3.weight"), rows, 64, 384,
+              y=rowmap(64, row64, Wp), x=rowmap(32, row32, Wp), x_tile_stride=row32, conv2d=(64, 32),
+              out_b=fp.g_ptr(pre + "spec_conv.3.bias"))
+    eng.gemm(ptr(g["sp_d2"]), ptr(w["spc2T"]), ptr(g["sp_dp1"]), rows, 32, 768, a=rowmap(64, row64, Wp), seg=(256, row64))
+    call("eg_spec_conv1_bwd", ptr(a["spimg"]), fp.p_ptr(pre + "spec_conv.0.weight"), fp.p_ptr(pre + "spec_conv.0.bias"),
+         ptr(g["sp_dp1"]), ptr(g["sp_part"]), nimg, F, nfr, dt, st)
+    call("eg_reduce_partials", ptr(g["sp_part"]), fp.g_ptr(pre + "spec_conv.0.weight"), 288, nimg, 320, 0, st)
+    call("eg_reduce_partials", ptr(g["sp_part"]) + 288 * 4, fp.g_ptr(pre + "spec_conv.0.bias"), 32, nimg, 320, 0, st)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -280,21 +327,7 @@ def backward(model, eng: Engine, dseq):
         sp, pre = eng.sp, "spectrogram_generator."
         F, nfr, Hp, Wp, nimg, rows = sp["F"], sp["nfr"], sp["Hp"], sp["Wp"], sp["nimg"], sp["rows"]
         off = (1 + n_ibs) * d * es
-        dmap = rowmap(d, S * d, Cn)
-        eng.wgrad(ptr(dseq) + off, ptr(a["sp_hp0"]), 0, nimg, d, 2 * d, y=dmap, linear=[pre + "proj.3"])
-        eng.gemm(ptr(dseq) + off, ptr(w["spp3T"]), ptr(g["sp_dhp0"]), nimg, 2 * d, d, a=dmap, gate=ptr(a["sp_hp0"]), gate_scale=sc01)
-        eng.wgrad(ptr(g["sp_dhp0"]), ptr(a["sp_pooled"]), 0, nimg, 2 * d, 1024, linear=[pre + "proj.0"])
-        eng.gemm(ptr(g["sp_dhp0"]), ptr(w["spp0T"]), ptr(g["sp_dpooled"]), nimg, 1024, 2 * d)
-        call("eg_spec_avgpool_bwd", ptr(a["sp_out2"]), ptr(g["sp_dpooled"]), ptr(g["sp_d2"]), nimg, Hp, Wp, dt, st)
-        row32, row64 = (Wp + 4) * 32, (Wp + 4) * 64
-        eng.wgrad(ptr(g["sp_d2"]) + (row64 + 64) * es, ptr(a["sp_p1"]), fp.g_ptr(pre + "spec_conv.3.weight"), rows, 64, 384,
-                  y=rowmap(64, row64, Wp), x=rowmap(32, row32, Wp), x_tile_stride=row32, conv2d=(64, 32),
-                  out_b=fp.g_ptr(pre + "spec_conv.3.bias"))
-        eng.gemm(ptr(g["sp_d2"]), ptr(w["spc2T"]), ptr(g["sp_dp1"]), rows, 32, 768, a=rowmap(64, row64, Wp), seg=(256, row64))
-        call("eg_spec_conv1_bwd", ptr(a["spimg"]), fp.p_ptr(pre + "spec_conv.0.weight"), fp.p_ptr(pre + "spec_conv.0.bias"),
-             ptr(g["sp_dp1"]), ptr(g["sp_part"]), nimg, F, nfr, dt, st)
-        call("eg_reduce_partials", ptr(g["sp_part"]), fp.g_ptr(pre + "spec_conv.0.weight"), 288, nimg, 320, 0, st)
-        call("eg_reduce_partials", ptr(g["sp_part"]) + 288 * 4, fp.g_ptr(pre + "spec_conv.0.bias"), 32, nimg, 320, 0, st)
+        spec_cnn_backward(eng, pre, ptr(dseq) + off, rowmap(d, S * d, Cn), sc01)
 
 
 def fire_spec_backward_hooks(model, eng: Engine):
