@@ -87,7 +87,7 @@ def test_f32_steps_match_the_cpu_restatement():
         assert float((gg - r["grads"]["gaze"].double()).norm() / r["grads"]["gaze"].double().norm()) < 3e-3
         st = model.eeg_encoder.engine(B, 1024, DEV).read_state()
         assert abs(st.grad_norm - float(r["norm"])) < 2e-3 * float(r["norm"])
-        assert abs(st.lr - hp["encoder_lr"] * warmup_cosine_factor(step, 2, 10)) < 1e-12
+        assert abs(st.lr - hp["encoder_lr"] * warmup_cosine_factor(step, 2, 10)) < 1e-9      # lr travels as fp32
     # parameters after three steps (first steps of Adam move every element by ~lr: compare the update's size and direction)
     for n, p in model.fusion.named_parameters():
         np.testing.assert_allclose(p.detach().cpu().numpy(), ref.fus[n].detach().numpy(), rtol=0, atol=2e-4, err_msg=n)
