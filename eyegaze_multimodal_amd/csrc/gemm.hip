@@ -890,6 +890,7 @@ static int launch_gemm_row(const eg_gemm_desc* d, hipStream_t s) {
 }
 
 int eg_rs_gemm_try(const eg_gemm_desc* d, hipStream_t s);   // rsgemm.hip: register-stationary row-stream kernel (K == 256)
+int eg_wide_gemm_try(const eg_gemm_desc* d, hipStream_t s); // widegemm.hip: 160x256 tile, LDS-DMA ring (N == 256)
 
 extern "C" int eg_gemm_nt(const eg_gemm_desc* d, void* stream) {
   EG_CHECK(d && d->A && d->W && (d->C || d->ln_mode == 2), "eg_gemm_nt: null operand");
@@ -912,6 +913,12 @@ extern "C" int eg_gemm_nt(const eg_gemm_desc* d, void* stream) {
   EG_CHECK(((uintptr_t)d->A | (uintptr_t)d->W | (uintptr_t)d->C) % 16 == 0, "eg_gemm_nt: operands must be 16-B aligned");
   hipStream_t s = (hipStream_t)stream;
   static const int use_rs = [] { const char* e = getenv("EYEGAZE_RS"); return e ? atoi(e) : 1; }();
+  static const int use_wide = [] { const char* e = getenv("EYEGAZE_WIDE"); return e ? atoi(e) : 1; }();
+  if (use_wide) {                                  // N == 256 (any K): one workgroup per 160 whole rows
+    const int rc = eg_wide_gemm_try(d, s);
+    if (rc == 0) return 0;
+    if (rc != -1) return eg_fail("wide gemm launch failed");
+  }
   if (use_rs) {
     const int rc = eg_rs_gemm_try(d, s);
     if (rc == 0) return 0;

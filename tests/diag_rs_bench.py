@@ -58,6 +58,11 @@ elif os.environ.get("RS_SHORT"):
     sys.exit(0)
 if os.environ.get("RS_SHORT") == "skip":
     M = 0
+if M and os.environ.get("WIDE_SHAPES"):
+    for K in (256, 768, 1024, 1792, 6400):
+        bench(M if K < 1792 else 32768, 256, K, residual=1)
+    bench(M, 256, 1024, residual=1, drop=0.1)
+    sys.exit(0)
 if M: bench(M, 768, 256)
 if M: bench(M, 256, 256, residual=1, drop=0.1)
 if M: bench(M, 256, 256, residual=1, drop=0.1, ln=1)

@@ -36,9 +36,8 @@ CASES = [
 ]
 
 
-def run_case(M, N, residual, gate, act, drop, out_pre, ln, seed=0):
+def run_case(M, N, residual, gate, act, drop, out_pre, ln, seed=0, K=256):
     g = torch.Generator(device="cpu").manual_seed(seed + M + N)
-    K = 256
     A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
     W = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
     b = torch.randn(N, generator=g).to(DEV)
@@ -93,7 +92,7 @@ def test_rs_gemm_is_bit_identical_to_the_tiled_kernel(case, tmp_path):
     dump = tmp_path / "ref.pt"
     code = ("import sys, torch; sys.path.insert(0, %r); from tests.test_gpu_rsgemm import run_case; "
             "_, r = run_case(*%r); torch.save(r, %r)" % (str(REPO), tuple(case), str(dump)))
-    env = dict(os.environ, EYEGAZE_RS="0")
+    env = dict(os.environ, EYEGAZE_RS="0", EYEGAZE_WIDE="0")
     subprocess.run([sys.executable, "-c", code], check=True, env=env, cwd=str(REPO))
     ref = torch.load(dump, weights_only=True)
     assert torch.equal(got["out"], ref["out"]), float((got["out"] - ref["out"]).abs().max())
