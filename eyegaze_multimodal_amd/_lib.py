@@ -52,6 +52,17 @@ class GemmDesc(C.Structure):
                 ("ln_drop1_site", C.c_uint32), ("ln_drop2_site", C.c_uint32)]
 
 
+class FfnDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("W1", C.c_void_p), ("W2", C.c_void_p), ("H", C.c_void_p), ("C", C.c_void_p),
+                ("bias1", C.c_void_p), ("bias2", C.c_void_p), ("gate", C.c_void_p), ("residual", C.c_void_p),
+                ("state", C.c_void_p),
+                ("lda", C.c_int64), ("ldh", C.c_int64), ("ldc", C.c_int64), ("ldg", C.c_int64), ("ldr", C.c_int64),
+                ("M", C.c_int32), ("F", C.c_int32), ("act1", C.c_int32), ("dtype", C.c_int32),
+                ("drop_h_p", C.c_float), ("drop_c1_p", C.c_float), ("drop_c2_p", C.c_float),
+                ("drop_h_site", C.c_uint32), ("drop_c1_site", C.c_uint32), ("drop_c2_site", C.c_uint32),
+                ("gate_scale", C.c_float)]
+
+
 class PackEntry(C.Structure):
     _fields_ = [("src", C.c_uint64), ("dst", C.c_uint64), ("rows", C.c_int32), ("cols", C.c_int32), ("ldd", C.c_int32),
                 ("mode", C.c_int32), ("blk0", C.c_int32), ("nblk", C.c_int32)]
@@ -86,6 +97,8 @@ SIGNATURES = {
     "eg_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eg_pack_convT_weight": [_P, _P, _I, _I, _I, _I, _I, _P],
     "eg_gemm_nt": [C.POINTER(GemmDesc), _P],
+    "eg_gemm_nt_route": [C.POINTER(GemmDesc)],
+    "eg_ffn_chain": [C.POINTER(FfnDesc), _P],
     "eg_gemm_tn": [C.POINTER(GemmTNDesc), _P],
     "eg_reduce_partials": [_P, _P, _L, _I, _L, _I, _P],
     "eg_gemm_tn_grouped": [_P, _I, _I, _I, _I, _I, _P],

@@ -1,0 +1,317 @@
+// Chained product pair of the position-wise feed-forward block (A:272) in ONE launch, forward and backward-data alike:
+//   H[M, F]   = epi1(A[M, 256] * W1[F, 256]^T)      epi1: + bias1, ReLU, gate (ReLU backward), dropout      -> stored (backward and
+//   C[M, 256] = epi2(H[M, F]   * W2[256, F]^T)                                                                 weight gradients need it)
+//   forward : A = y1, W1 = linear1, W2 = linear2, epi2 = + bias2, dropout x2, + residual (the A rows themselves) -> r2
+//   backward: A = dY, W1 = linear2^T, gate = saved hidden rows, W2 = linear1^T, epi2 = + residual (dr)           -> dy1
+// As two launches the pair moves H through HBM twice (write, read back: 2 x 68 MB per layer and direction at the benchmark
+// size) and A / the residual once more; here the hidden rows only leave the chip once, as the stored result.
+//
+// Design (gfx950), one 512-thread workgroup (8 waves = 2 row halves x 4 column groups, 2 waves per SIMD) per 160 rows:
+//   * the A tile [160 x 256] stays in LDS for the whole launch (80 KB, LDS-DMA, 16-B chunks XOR-swizzled by row & 7); it is the
+//     B operand of every product-1 MFMA and, in the forward pass, the residual of the final epilogue (no second HBM read);
+//   * the hidden dimension is walked in chunks of 128 columns: product 1 gives a wave 80 x 32 of the chunk (5 x 2 accumulator
+//     tiles over K = 256), its epilogue writes the 16-bit chunk into one of TWO 40 KB LDS buffers (one barrier per chunk), from
+//     where (a) all threads stream it to HBM as whole 256-B row segments and (b) product 2 reads it back as the B operand of
+//     the wave's 80 x 64 part of C (5 x 4 accumulator tiles that live in registers across all chunks);
+//   * WEIGHTS NEVER TOUCH LDS: a wave's W1 / W2 fragments (16 rows x 64 B per instruction, L2-resident: 1 MB per layer) are
+//     loaded straight into registers through rolling rings four / two k-steps ahead of their MFMAs, so the LDS pipe only carries
+//     the activation fragments: 0.5 KB per MFMA in product 1, 0.25 KB in product 2 -- below the 0.5 KB / MFMA at which LDS and
+//     matrix pipes balance, which the 128 x 128 and 160 x 256 tiles (weights through LDS) sit on;
+//   * the backward gate (saved hidden rows, zero where ReLU / dropout cut) is requested into registers at the start of a chunk.
+// Arithmetic: the same k-ordered chains of v_mfma_f32_16x16x32 as eg_gemm_nt's kernels and the same epilogue order and dropout
+// indices, so H and C are bit-identical to the two-launch path.
+#include "common.h"
+
+namespace {
+
+constexpr int FR = 160;                       // rows per workgroup
+constexpr int FD = 256;                       // d_model: K of product 1, N of product 2
+constexpr int FC = 128;                       // hidden columns per chunk
+constexpr int F_XT = FR * FD * 2;             // 81,920 B
+constexpr int F_HT = FR * FC * 2;             // 40,960 B
+constexpr int F_LDS = F_XT + 2 * F_HT;        // 163,840 B = the whole LDS of a CU
+constexpr int F_TP = 68;                      // fp32 image pitch of the final epilogue (floats)
+
+template <typename T>
+struct FfnArgs {
+  const T* A; const T* W1; const T* W2; T* H; T* C; const float* bias1; const float* bias2; const T* gate; const T* residual;
+  const eg_step_state* st;
+  long long lda, ldh, ldc, ldg, ldr;
+  int M, F, ldw1, ldw2, relu, res_in_lds;
+  DropCfg dh, dc1, dc2;
+  float gate_scale;
+};
+
+__device__ __forceinline__ void fdma16(const char* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ u32x2 f_pack4(const float v[4]) {
+  u32x2 o;
+  o[0] = H16<T>::pack2(v[0], v[1]);
+  o[1] = H16<T>::pack2(v[2], v[3]);
+  return o;
+}
+
+template <typename T, int GATE>
+__global__ __launch_bounds__(512, 2) void ffn_chain_kernel(FfnArgs<T> p) {
+  typedef typename H16<T>::frag frag;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const xt = smem;
+  char* const hb = smem + F_XT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int m0 = blockIdx.x * FR;
+  const int nch = p.F / FC;
+
+  // ---- A tile: instruction q moves rows 2q, 2q+1 (lane -> row half lane/32, LDS chunk position lane%32 holding global chunk
+  //      pos ^ (row & 7)); wave w issues q = w, w+8, .. (10 each) ----
+  {
+    const int half = lane >> 5, pos = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int q = wave + 8 * i;
+      const int r = 2 * q + half;
+      const int row = min(m0 + r, p.M - 1);
+      fdma16((const char*)(p.A + (size_t)row * (size_t)p.lda) + ((pos ^ (r & 7)) << 4), xt + q * 1024);
+    }
+  }
+
+  // ---- weight fragment streams (global -> registers).  A-operand rows: W1 row = hidden unit, W2 row = output column ----
+  const T* const w1p = p.W1 + (size_t)(32 * wn + l15) * (size_t)p.ldw1 + 8 * g4;   // + (128 c + 16 j) * ldw1 + 32 s
+  const T* const w2p = p.W2 + (size_t)(64 * wn + l15) * (size_t)p.ldw2 + 8 * g4;   // + 16 j * ldw2 + 128 c + 32 s
+  frag w1r[4][2], w2r[2][4];
+  auto req_w1 = [&](int c, int s, int slot) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) w1r[slot][j] = *(const frag*)(w1p + (size_t)(FC * c + 16 * j) * (size_t)p.ldw1 + 32 * s);
+  };
+  auto req_w2 = [&](int c, int s, int slot) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w2r[slot][j] = *(const frag*)(w2p + (size_t)(16 * j) * (size_t)p.ldw2 + FC * c + 32 * s);
+  };
+#pragma unroll
+  for (int s = 0; s < 4; ++s) req_w1(0, s, s);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) req_w2(0, s, s);
+
+  f32x4 acc2[5][4];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint32_t seed_lo = 0, seed_hi = 0;
+  if (p.dh.thresh | p.dc1.thresh | p.dc2.thresh) { seed_lo = p.st->seed_lo; seed_hi = p.st->seed_hi; }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's part of the A tile has landed (and the first fragments)
+  __syncthreads();                                           // ... and everybody else's
+
+  const int rbase = 80 * wm + l15;                           // row of tile i within the workgroup: rbase + 16 i
+  const int sw7 = l15 & 7;
+
+  for (int c = 0; c < nch; ++c) {
+    char* const hc = hb + (c & 1) * F_HT;
+    const int f0 = FC * c + 32 * wn + 4 * g4;                // hidden column of accumulator register q of tile j: f0 + 16 j + q
+
+    // epilogue-1 operands of this chunk, requested before the MFMAs that hide them
+    float b1[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b1[j][q] = 0.f;
+      if (p.bias1) load4(p.bias1 + f0 + 16 * j, b1[j]);
+    }
+    u32x2 gt[5][2];
+    if (GATE) {
+      int rb = rbase;
+      asm volatile("" : "+v"(rb));                             // addresses are recomputed per chunk, not kept (and spilled) across the loop
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int m = min(m0 + rb + 16 * i, p.M - 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) gt[i][j] = *(const u32x2*)(p.gate + (size_t)m * (size_t)p.ldg + f0 + 16 * j);
+      }
+    }
+
+    // ---- product 1: acc1[i][j] = sum_k W1[hidden][k] * A[row][k] ----
+    f32x4 acc1[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      frag xf[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) xf[i] = *(const frag*)(xt + (rbase + 16 * i) * 512 + (((4 * s + g4) ^ sw7) << 4));
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc1[i][j] = H16<T>::mfma(w1r[s & 3][j], xf[i], acc1[i][j]);
+      // the ring slot just consumed is refilled four k-steps ahead (running on into the next chunk)
+      if (s < 4) req_w1(c, s + 4, s & 3);
+      else if (c + 1 < nch) req_w1(c + 1, s - 4, s & 3);
+    }
+
+    // ---- epilogue 1 (MFMA layout: lane holds 4 consecutive hidden columns of row l15) -> 16-bit chunk image in LDS ----
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int r = rbase + 16 * i;
+      const uint32_t m = (uint32_t)(m0 + r);                   // rows beyond M stay on chip (never stored): no clamp needed
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] = acc1[i][j][q] + b1[j][q];
+          if (p.relu) v[q] = fmaxf(v[q], 0.f);
+        }
+        if (GATE) {
+          float gv[4];
+          load4((const T*)&gt[i][j], gv);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = gv[q] > 0.f ? v[q] * p.gate_scale : 0.f;
+        }
+        eg_dropout_run<4>(v, p.dh, seed_lo, seed_hi, m * (uint32_t)p.F + (uint32_t)(f0 + 16 * j));
+        const int hcol = 32 * wn + 16 * j + 4 * g4;            // column within the chunk
+        *(u32x2*)(hc + r * 256 + (((hcol >> 3) ^ sw7) << 4) + ((hcol & 4) << 1)) = f_pack4<T>(v);
+      }
+    }
+    __syncthreads();        // chunk c is complete in LDS; nobody reads buffer (c+1)&1 (chunk c-1) any more
+
+    // ---- the stored result: whole 256-B row segments of the chunk, 16 B per thread ----
+    int tq = tid >> 4;
+    asm volatile("" : "+v"(tq));                               // (same: no loop-invariant address registers)
+#pragma unroll
+    for (int ps = 0; ps < 5; ++ps) {
+      const int r = 32 * ps + tq, ch = tid & 15;
+      const u32x4 o = *(const u32x4*)(hc + r * 256 + ((ch ^ (r & 7)) << 4));
+      if (m0 + r < p.M) *(u32x4*)(p.H + (size_t)(m0 + r) * (size_t)p.ldh + FC * c + 8 * ch) = o;
+    }
+
+    // ---- product 2: acc2[i][j] += sum_h W2[col][h] * H[row][h] over the chunk's 128 hidden columns ----
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      frag hf[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) hf[i] = *(const frag*)(hc + (rbase + 16 * i) * 256 + (((4 * s + g4) ^ sw7) << 4));
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc2[i][j] = H16<T>::mfma(w2r[s & 1][j], hf[i], acc2[i][j]);
+      if (s < 2) req_w2(c, s + 2, s & 1);
+      else if (c + 1 < nch) req_w2(c + 1, s - 2, s & 1);
+    }
+  }
+  __syncthreads();          // every wave has left the chunk buffers: they become the fp32 image of the final epilogue
+
+  // ---- epilogue 2: per 16-row tile through a wave-private fp32 image [16][68]; a lane then owns 16 consecutive columns of a row ----
+  float* timg = (float*)(hb + wave * (16 * F_TP * 4));
+  const int er = lane >> 2, ec = lane & 3;
+  const int n = 64 * wn + 16 * ec;
+  float bv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bv[j] = 0.f;
+  if (p.bias2) { load8(p.bias2 + n, bv); load8(p.bias2 + n + 8, bv + 8); }
+  u32x4 eraw[5][2];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    eraw[i][0] = (u32x4){0u, 0u, 0u, 0u};
+    eraw[i][1] = (u32x4){0u, 0u, 0u, 0u};
+    const int r = 80 * wm + 16 * i + er;
+    if (p.res_in_lds) {
+      eraw[i][0] = *(const u32x4*)(xt + r * 512 + ((((n >> 3)) ^ (r & 7)) << 4));
+      eraw[i][1] = *(const u32x4*)(xt + r * 512 + ((((n >> 3) + 1) ^ (r & 7)) << 4));
+    } else if (p.residual && m0 + r < p.M) {
+      const T* pe = p.residual + (size_t)(m0 + r) * (size_t)p.ldr + n;
+      eraw[i][0] = *(const u32x4*)pe;
+      eraw[i][1] = *(const u32x4*)(pe + 8);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int m = m0 + 80 * wm + 16 * i + er;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(f32x4*)(timg + l15 * F_TP + 16 * j + 4 * g4) = acc2[i][j];
+    if (m0 + 80 * wm + 16 * i >= p.M) break;                 // wave-uniform: tiles wholly beyond M
+    float v[16];
+    load8(timg + er * F_TP + 16 * ec, v);
+    load8(timg + er * F_TP + 16 * ec + 8, v + 8);
+    if (m < p.M) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] += bv[j];
+      if (p.dc1.thresh | p.dc2.thresh) {
+        const uint32_t idx = (uint32_t)m * (uint32_t)FD + (uint32_t)n;
+        float (&v0)[8] = *(float (*)[8])v;
+        float (&v1)[8] = *(float (*)[8])(v + 8);
+        eg_dropout_run<8>(v0, p.dc1, seed_lo, seed_hi, idx);
+        eg_dropout_run<8>(v0, p.dc2, seed_lo, seed_hi, idx);
+        eg_dropout_run<8>(v1, p.dc1, seed_lo, seed_hi, idx + 8);
+        eg_dropout_run<8>(v1, p.dc2, seed_lo, seed_hi, idx + 8);
+      }
+      if (p.residual) {
+        float rv[16];
+        load8((const T*)&eraw[i][0], rv);
+        load8((const T*)&eraw[i][1], rv + 8);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] += rv[j];
+      }
+      T* pc = p.C + (size_t)m * (size_t)p.ldc + n;
+      store8(pc, v);
+      store8(pc + 8, v + 8);
+    }
+  }
+}
+
+template <typename T>
+static int ffn_launch(const eg_ffn_desc* d, hipStream_t s) {
+  FfnArgs<T> p;
+  p.A = (const T*)d->A; p.W1 = (const T*)d->W1; p.W2 = (const T*)d->W2; p.H = (T*)d->H; p.C = (T*)d->C;
+  p.bias1 = d->bias1; p.bias2 = d->bias2; p.gate = (const T*)d->gate; p.residual = (const T*)d->residual; p.st = d->state;
+  p.lda = d->lda; p.ldh = d->ldh; p.ldc = d->ldc; p.ldg = d->ldg; p.ldr = d->ldr;
+  p.M = d->M; p.F = d->F; p.ldw1 = FD; p.ldw2 = d->F;
+  p.relu = d->act1 == EG_ACT_RELU;
+  p.res_in_lds = d->residual && d->residual == d->A && d->ldr == d->lda;
+  p.dh = make_drop(d->drop_h_p, d->drop_h_site);
+  p.dc1 = make_drop(d->drop_c1_p, d->drop_c1_site);
+  p.dc2 = make_drop(d->drop_c2_p, d->drop_c2_site);
+  p.gate_scale = d->gate_scale == 0.f ? 1.0f : d->gate_scale;
+  const dim3 grid((d->M + FR - 1) / FR), blk(512);
+#define FFN_LAUNCH(G_)                                                                                                 \
+  do {                                                                                                                 \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      (void)hipFuncSetAttribute((const void*)ffn_chain_kernel<T, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS); \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((ffn_chain_kernel<T, G_>), grid, blk, F_LDS, s, p);                                             \
+  } while (0)
+  if (d->gate) FFN_LAUNCH(1); else FFN_LAUNCH(0);
+#undef FFN_LAUNCH
+  EG_LAUNCH_CHECK("ffn_chain");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int eg_ffn_chain(const eg_ffn_desc* d, void* stream) {
+  EG_CHECK(d && d->A && d->W1 && d->W2 && d->H && d->C, "eg_ffn_chain: null operand");
+  EG_CHECK(d->dtype == EG_BF16 || d->dtype == EG_F16, "eg_ffn_chain: 16-bit compute dtypes only (got %d)", d->dtype);
+  EG_CHECK(d->M > 0 && d->F > 0 && d->F % FC == 0, "eg_ffn_chain: M=%d, F=%d (F must be a multiple of %d)", d->M, d->F, FC);
+  EG_CHECK(d->act1 == EG_ACT_NONE || d->act1 == EG_ACT_RELU, "eg_ffn_chain: act1 %d", d->act1);
+  EG_CHECK(d->lda >= FD && d->ldc >= FD && d->ldh >= d->F && d->lda % 8 == 0 && d->ldc % 8 == 0 && d->ldh % 8 == 0,
+           "eg_ffn_chain: row strides must be 16-B multiples covering the rows");
+  EG_CHECK(!d->gate || (d->ldg >= d->F && d->ldg % 4 == 0), "eg_ffn_chain: gate stride");
+  EG_CHECK(!d->residual || (d->ldr >= FD && d->ldr % 8 == 0), "eg_ffn_chain: residual stride");
+  EG_CHECK((long long)d->M * d->F < (1ll << 32), "eg_ffn_chain: M*F exceeds the 32-bit dropout index");
+  const float ps[3] = {d->drop_h_p, d->drop_c1_p, d->drop_c2_p};
+  for (float q : ps) EG_CHECK(q >= 0.f && q < 1.f, "eg_ffn_chain: dropout p");
+  EG_CHECK((ps[0] == 0.f && ps[1] == 0.f && ps[2] == 0.f) || d->state, "eg_ffn_chain: dropout needs a step state");
+  EG_CHECK(((uintptr_t)d->A | (uintptr_t)d->W1 | (uintptr_t)d->W2 | (uintptr_t)d->H | (uintptr_t)d->C | (uintptr_t)d->gate |
+            (uintptr_t)d->residual) % 16 == 0, "eg_ffn_chain: operands must be 16-B aligned");
+  hipStream_t s = (hipStream_t)stream;
+  return d->dtype == EG_F16 ? ffn_launch<f16_t>(d, s) : ffn_launch<bf16_t>(d, s);
+}

@@ -892,6 +892,20 @@ static int launch_gemm_row(const eg_gemm_desc* d, hipStream_t s) {
 int eg_rs_gemm_try(const eg_gemm_desc* d, hipStream_t s);   // rsgemm.hip: register-stationary row-stream kernel (K == 256)
 int eg_wide_gemm_try(const eg_gemm_desc* d, hipStream_t s); // widegemm.hip: 160x256 tile, LDS-DMA ring (N == 256)
 
+bool eg_rs_gemm_ok(const eg_gemm_desc* d);
+bool eg_wide_gemm_ok(const eg_gemm_desc* d);
+static int gemm_knob(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 1; }
+
+// which kernel eg_gemm_nt launches for this descriptor (measurement aid: bench.py attributes its per-launch timings with it)
+extern "C" int eg_gemm_nt_route(const eg_gemm_desc* d) {
+  if (!d) return -1;
+  static const int use_rs = gemm_knob("EYEGAZE_RS"), use_wide = gemm_knob("EYEGAZE_WIDE");
+  if (use_wide && eg_wide_gemm_ok(d)) return EG_ROUTE_WIDE;
+  if (use_rs && eg_rs_gemm_ok(d)) return EG_ROUTE_ROWSTREAM;
+  if (d->ln_mode != 0 || d->row_tile) return EG_ROUTE_ROWTILE;
+  return EG_ROUTE_TILED;
+}
+
 extern "C" int eg_gemm_nt(const eg_gemm_desc* d, void* stream) {
   EG_CHECK(d && d->A && d->W && (d->C || d->ln_mode == 2), "eg_gemm_nt: null operand");
   EG_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "eg_gemm_nt: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -912,8 +926,7 @@ extern "C" int eg_gemm_nt(const eg_gemm_desc* d, void* stream) {
   EG_CHECK((long long)d->M * d->N < (1ll << 32), "eg_gemm_nt: M*N exceeds the 32-bit dropout index");
   EG_CHECK(((uintptr_t)d->A | (uintptr_t)d->W | (uintptr_t)d->C) % 16 == 0, "eg_gemm_nt: operands must be 16-B aligned");
   hipStream_t s = (hipStream_t)stream;
-  static const int use_rs = [] { const char* e = getenv("EYEGAZE_RS"); return e ? atoi(e) : 1; }();
-  static const int use_wide = [] { const char* e = getenv("EYEGAZE_WIDE"); return e ? atoi(e) : 1; }();
+  static const int use_rs = gemm_knob("EYEGAZE_RS"), use_wide = gemm_knob("EYEGAZE_WIDE");
   if (use_wide) {                                  // N == 256 (any K): one workgroup per 160 whole rows
     const int rc = eg_wide_gemm_try(d, s);
     if (rc == 0) return 0;

@@ -341,19 +341,24 @@ static int rs_gemm_launch(const eg_gemm_desc* d, hipStream_t s, int cus) {
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-int eg_rs_gemm_try(const eg_gemm_desc* d, hipStream_t s) {
-  if ((d->dtype != EG_BF16 && d->dtype != EG_F16) || d->K != 256 || d->N % 256 != 0 || d->ldw != 256) return -1;
-  if (d->a.rows_per_group || d->c.rows_per_group || d->r.rows_per_group || d->p.rows_per_group) return -1;
-  if (d->a_seg_len || d->ln_mode || d->row_tile || d->act == EG_ACT_GELU) return -1;
-  if (d->residual && d->gate) return -1;
-  if (!d->C) return -1;
-  if (d->a.row_stride % 8 || d->c.row_stride % 8 || (d->residual && d->r.row_stride % 8) || (d->out_pre && d->p.row_stride % 8)) return -1;
+bool eg_rs_gemm_ok(const eg_gemm_desc* d) {
+  if ((d->dtype != EG_BF16 && d->dtype != EG_F16) || d->K != 256 || d->N % 256 != 0 || d->ldw != 256) return false;
+  if (d->a.rows_per_group || d->c.rows_per_group || d->r.rows_per_group || d->p.rows_per_group) return false;
+  if (d->a_seg_len || d->ln_mode || d->row_tile || d->act == EG_ACT_GELU) return false;
+  if (d->residual && d->gate) return false;
+  if (!d->C) return false;
+  if (d->a.row_stride % 8 || d->c.row_stride % 8 || (d->residual && d->r.row_stride % 8) || (d->out_pre && d->p.row_stride % 8)) return false;
   {
     const long long lim = 1ll << 32, M = d->M;
     if (M * d->a.row_stride >= lim || M * d->c.row_stride >= lim || (d->residual && M * d->r.row_stride >= lim) ||
-        (d->out_pre && M * d->p.row_stride >= lim)) return -1;
+        (d->out_pre && M * d->p.row_stride >= lim)) return false;
   }
-  if (((uintptr_t)d->A | (uintptr_t)d->W | (uintptr_t)d->C | (uintptr_t)d->residual | (uintptr_t)d->gate | (uintptr_t)d->out_pre) % 16) return -1;
+  if (((uintptr_t)d->A | (uintptr_t)d->W | (uintptr_t)d->C | (uintptr_t)d->residual | (uintptr_t)d->gate | (uintptr_t)d->out_pre) % 16) return false;
+  return true;
+}
+
+int eg_rs_gemm_try(const eg_gemm_desc* d, hipStream_t s) {
+  if (!eg_rs_gemm_ok(d)) return -1;
   static int cus = 0;
   if (!cus) {
     int dev = 0;

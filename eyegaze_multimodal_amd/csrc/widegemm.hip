@@ -127,6 +127,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_wide_kernel(WideNT<T> p) {
 #pragma unroll
   for (int j = 0; j < 16; ++j) bv[j] = 0.f;
   if (p.bias) { load8(p.bias + n, bv); load8(p.bias + n + 8, bv + 8); }
+  // the epilogue operand (residual, else gate) of all of this lane's rows is requested up front: one exposed latency, not five
+  const T* const eop = p.residual ? p.residual : p.gate;
+  const RowMap& emap = p.residual ? p.r : p.c;
+  u32x4 eraw[5][2];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    eraw[i][0] = (u32x4){0u, 0u, 0u, 0u};
+    eraw[i][1] = (u32x4){0u, 0u, 0u, 0u};
+    const int m = m0 + 80 * wm + 16 * i + er;
+    if (eop && m < p.M) {
+      const T* pe = eop + row_off(emap, m) + n;
+      eraw[i][0] = *(const u32x4*)pe;
+      eraw[i][1] = *(const u32x4*)(pe + 8);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const int m = m0 + 80 * wm + 16 * i + er;
@@ -142,8 +157,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_wide_kernel(WideNT<T> p) {
       const long long coff = row_off(p.c, m) + n;
       if (p.gate) {
         float gv[16];
-        load8(p.gate + coff, gv);
-        load8(p.gate + coff + 8, gv + 8);
+        if (!p.residual) {
+          load8((const T*)&eraw[i][0], gv);
+          load8((const T*)&eraw[i][1], gv + 8);
+        } else {
+          load8(p.gate + coff, gv);
+          load8(p.gate + coff + 8, gv + 8);
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = gv[j] > 0.f ? v[j] * p.gate_scale : 0.f;
       }
@@ -163,9 +183,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_wide_kernel(WideNT<T> p) {
       }
       if (p.residual) {
         float rv[16];
-        const T* pr = p.residual + row_off(p.r, m) + n;
-        load8(pr, rv);
-        load8(pr + 8, rv + 8);
+        load8((const T*)&eraw[i][0], rv);
+        load8((const T*)&eraw[i][1], rv + 8);
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] += rv[j];
       }
@@ -206,10 +225,14 @@ static int wide_launch(const eg_gemm_desc* d, hipStream_t s) {
 }  // namespace
 
 // eligibility + launch; returns -1 when the product does not fit this kernel (caller falls back)
+bool eg_wide_gemm_ok(const eg_gemm_desc* d) {
+  if ((d->dtype != EG_BF16 && d->dtype != EG_F16) || d->N != WBN || d->K % 64 != 0 || d->K < 128) return false;
+  if (d->a_seg_len || d->ln_mode || d->row_tile || !d->C) return false;
+  if (d->M < 1024) return false;               // the head products (M = batch) keep the 128x128 tile
+  return d->ldw % 8 == 0;
+}
+
 int eg_wide_gemm_try(const eg_gemm_desc* d, hipStream_t s) {
-  if ((d->dtype != EG_BF16 && d->dtype != EG_F16) || d->N != WBN || d->K % 64 != 0 || d->K < 128) return -1;
-  if (d->a_seg_len || d->ln_mode || d->row_tile || !d->C) return -1;
-  if (d->M < 1024) return -1;                  // the head products (M = batch) keep the 128x128 tile
-  if (d->ldw % 8) return -1;
+  if (!eg_wide_gemm_ok(d)) return -1;
   return d->dtype == EG_F16 ? wide_launch<f16_t>(d, s) : wide_launch<bf16_t>(d, s);
 }

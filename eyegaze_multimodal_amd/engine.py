@@ -314,13 +314,16 @@ class Engine:
         """ln: LayerNorm fused into the epilogue of an N == 256 product (eg_gemm_desc.ln_*):
         dict(mode=1, gamma, beta, out, stats) or dict(mode=2, gamma, x, stats, out, out2, partial, d1, d2)."""
         probe = self.probes.get(tag) if tag else None
-        if self.probe_all is not None:      # bench.py: HIP events around EVERY gemm_nt launch of the timed region
+        dsc = self._gemm_desc(A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2,
+                              gate_scale, seg, ln)
+        if self.probe_all is not None:      # bench.py: HIP events around EVERY eg_gemm_nt launch of the timed region
             probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.probe_all.append((probe[0], probe[1], 2.0 * M * N * K,
-                                   self._gemm_bytes(M, N, K, a, seg, residual, gate, out_pre, ln, Cout), (M, N, K)))
+                                   self._gemm_bytes(M, N, K, a, seg, residual, gate, out_pre, ln, Cout), (M, N, K),
+                                   L.lib().eg_gemm_nt_route(C.byref(dsc))))
         if probe:
             probe[0].record(torch.cuda.current_stream(self.device))
-        self._gemm(A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale, seg, ln)
+        call("eg_gemm_nt", C.byref(dsc), self.stream)
         if probe:
             probe[1].record(torch.cuda.current_stream(self.device))
 
@@ -359,8 +362,8 @@ class Engine:
             ins += 1 if ln["mode"] == 2 else 0
         return float(es * (a_elems + N * K + (outs + ins) * M * N) + 4 * N)
 
-    def _gemm(self, A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale,
-              seg=(0, 0), ln=None):
+    def _gemm_desc(self, A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale,
+                   seg=(0, 0), ln=None):
         dsc = GemmDesc()
         if ln:
             dsc.ln_mode, dsc.ln_gamma, dsc.ln_stats, dsc.ln_out = ln["mode"], ln["gamma"], ln["stats"], ln["out"]
@@ -383,7 +386,7 @@ class Engine:
         dsc.drop1_p, dsc.drop1_site = drop1
         dsc.drop2_p, dsc.drop2_site = drop2
         dsc.gate_scale = gate_scale
-        call("eg_gemm_nt", C.byref(dsc), self.stream)
+        return dsc
 
     def wgrad(self, dY, X, out_w, M, N, K, *, y=None, x=None, out_b=0, conv=None, split_out=None, x_tile_stride=0,
               conv2d=None, linear=None):

@@ -159,6 +159,40 @@ typedef struct eg_gemm_desc {
   uint32_t ln_drop1_site, ln_drop2_site;
 } eg_gemm_desc;
 int eg_gemm_nt(const eg_gemm_desc* d, void* stream);
+/* Which kernel eg_gemm_nt launches for `d` (no launch; a measurement aid so that per-launch timings can be attributed):
+ * EG_ROUTE_TILED gemm_nt_kernel (128x128 tile), EG_ROUTE_WIDE gemm_nt_wide_kernel (160x256, N == 256),
+ * EG_ROUTE_ROWSTREAM rs_gemm_kernel (K == 256, register-stationary weights), EG_ROUTE_ROWTILE gemm_nt_row_kernel. */
+enum { EG_ROUTE_TILED = 0, EG_ROUTE_WIDE = 1, EG_ROUTE_ROWSTREAM = 2, EG_ROUTE_ROWTILE = 3 };
+int eg_gemm_nt_route(const eg_gemm_desc* d);
+
+/* ---------------------------------------------------------------------------------------------
+ * eg_ffn_chain — the two products of the position-wise feed-forward block (A:264-272) in one launch, d_model == 256:
+ *   H[M,F]   = drop_h(gate(act1(A[M,256] * W1[F,256]^T + bias1)))       stored (backward and the weight gradients read it)
+ *   C[M,256] = drop_c2(drop_c1(H * W2[256,F]^T + bias2)) + residual
+ *   forward  (A:272 linear1 -> ReLU -> dropout -> linear2, then A:294 dropout + residual): A = residual = LayerNorm-1 rows
+ *   backward-data of the same block: A = dY, W1 = linear2^T, gate = the saved H rows (value zeroed where gate <= 0, else
+ *   scaled by gate_scale), W2 = linear1^T, residual = the gradient arriving on the skip path.
+ *   Bit-identical to the two eg_gemm_nt launches it replaces (same MFMA chains, epilogue order and dropout indices m*N + n);
+ *   the hidden rows cross HBM once (the stored H) instead of three times.  16-bit dtypes, F % 128 == 0, strides in elements.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct eg_ffn_desc {
+  const void* A;        /* [M, 256], row stride lda */
+  const void* W1;       /* [F, 256] row-major */
+  const void* W2;       /* [256, F] row-major */
+  void* H;              /* [M, F], row stride ldh */
+  void* C;              /* [M, 256], row stride ldc */
+  const float* bias1;   /* [F] or NULL */
+  const float* bias2;   /* [256] or NULL */
+  const void* gate;     /* [M, F], row stride ldg, or NULL */
+  const void* residual; /* [M, 256], row stride ldr, or NULL; may alias A (then it is taken from the on-chip A tile) */
+  const eg_step_state* state;
+  int64_t lda, ldh, ldc, ldg, ldr;
+  int32_t M, F, act1, dtype;
+  float drop_h_p, drop_c1_p, drop_c2_p;
+  uint32_t drop_h_site, drop_c1_site, drop_c2_site;
+  float gate_scale;
+} eg_ffn_desc;
+int eg_ffn_chain(const eg_ffn_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * eg_gemm_tn — weight-gradient product  dW[N,K] = sum_m dY[m,n] * X[m,k]  (fp32 result)
