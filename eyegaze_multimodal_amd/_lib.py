@@ -54,7 +54,8 @@ class GemmDesc(C.Structure):
 
 class FfnDesc(C.Structure):
     _fields_ = [("A", C.c_void_p), ("W1", C.c_void_p), ("W2", C.c_void_p), ("H", C.c_void_p), ("C", C.c_void_p),
-                ("bias1", C.c_void_p), ("bias2", C.c_void_p), ("gate", C.c_void_p), ("residual", C.c_void_p),
+                ("bias1", C.c_void_p), ("bias2", C.c_void_p), ("gate", C.c_void_p), ("gate_bits_out", C.c_void_p),
+                ("gate_bits_in", C.c_void_p), ("residual", C.c_void_p),
                 ("state", C.c_void_p),
                 ("lda", C.c_int64), ("ldh", C.c_int64), ("ldc", C.c_int64), ("ldg", C.c_int64), ("ldr", C.c_int64),
                 ("M", C.c_int32), ("F", C.c_int32), ("act1", C.c_int32), ("dtype", C.c_int32),
@@ -170,6 +171,14 @@ def lib() -> C.CDLL:
         fn.restype = C.c_int
     _lib = l
     return l
+
+
+def gate_bits_bytes(M: int, F: int) -> int:
+    """Size of the gate bit image eg_ffn_chain writes / reads for an [M, F] hidden tensor (eg_ffn_gate_bits_bytes)."""
+    l = lib()
+    l.eg_ffn_gate_bits_bytes.restype = C.c_int64
+    l.eg_ffn_gate_bits_bytes.argtypes = [C.c_int, C.c_int]
+    return int(l.eg_ffn_gate_bits_bytes(M, F))
 
 
 def exported_symbols():

@@ -6,38 +6,47 @@
 // As two launches the pair moves H through HBM twice (write, read back: 2 x 68 MB per layer and direction at the benchmark
 // size) and A / the residual once more; here the hidden rows only leave the chip once, as the stored result.
 //
-// Design (gfx950), one 512-thread workgroup (8 waves = 2 row halves x 4 column groups, 2 waves per SIMD) per 160 rows:
-//   * the A tile [160 x 256] stays in LDS for the whole launch (80 KB, LDS-DMA, 16-B chunks XOR-swizzled by row & 7); it is the
+// Design (gfx950), one 256-thread workgroup (4 waves = 4 column groups, one per SIMD) per 80 rows, TWO workgroups per CU (80 KB
+// of LDS each): the two row halves of a CU share nothing, so they run as independent workgroups whose phases drift apart -- one's
+// MFMA bursts sit beside the other's epilogue / barrier / store phases (as one 512-thread workgroup every wave hit the same
+// barrier and the matrix pipe idled through each epilogue):
+//   * the A tile [80 x 256] stays in LDS for the whole launch (40 KB, LDS-DMA, 16-B chunks XOR-swizzled by row & 7); it is the
 //     B operand of every product-1 MFMA and, in the forward pass, the residual of the final epilogue (no second HBM read);
 //   * the hidden dimension is walked in chunks of 128 columns: product 1 gives a wave 80 x 32 of the chunk (5 x 2 accumulator
-//     tiles over K = 256), its epilogue writes the 16-bit chunk into one of TWO 40 KB LDS buffers (one barrier per chunk), from
+//     tiles over K = 256), its epilogue writes the 16-bit chunk into one of TWO 20 KB LDS buffers (one barrier per chunk), from
 //     where (a) all threads stream it to HBM as whole 256-B row segments and (b) product 2 reads it back as the B operand of
 //     the wave's 80 x 64 part of C (5 x 4 accumulator tiles that live in registers across all chunks);
-//   * WEIGHTS NEVER TOUCH LDS: a wave's W1 / W2 fragments (16 rows x 64 B per instruction, L2-resident: 1 MB per layer) are
-//     loaded straight into registers through rolling rings four / two k-steps ahead of their MFMAs, so the LDS pipe only carries
+//   * WEIGHTS NEVER TOUCH LDS: a wave's W1 / W2 fragments (pre-packed in fragment order: one contiguous 1-KB read each,
+//     L2-resident, 1 MB per layer) go straight into registers through rolling rings four / two k-steps ahead, so the LDS pipe only carries
 //     the activation fragments: 0.5 KB per MFMA in product 1, 0.25 KB in product 2 -- below the 0.5 KB / MFMA at which LDS and
 //     matrix pipes balance, which the 128 x 128 and 160 x 256 tiles (weights through LDS) sit on;
-//   * the backward gate (saved hidden rows, zero where ReLU / dropout cut) is requested into registers at the start of a chunk.
+//   * the backward gate ("the saved hidden value is > 0": ReLU and dropout cut together) travels as ONE BIT per element: the
+//     forward launch writes it in MFMA-lane order (40 bits of one 8-byte word per lane and chunk), the backward launch of the
+//     same geometry reads one word per lane and chunk, two chunks ahead -- 4.3 MB per layer instead of re-reading the 68 MB of
+//     hidden rows, and no HBM-latency loads in front of the weight fragments in the waves' in-order vmcnt queues (with the gate
+//     rows themselves loaded into registers the backward form took 75 us against 68 us for the two launches).  The hidden
+//     rows themselves remain accepted as the gate (eg_ffn_desc.gate) for callers without a forward launch of this kernel.
 // Arithmetic: the same k-ordered chains of v_mfma_f32_16x16x32 as eg_gemm_nt's kernels and the same epilogue order and dropout
 // indices, so H and C are bit-identical to the two-launch path.
 #include "common.h"
 
 namespace {
 
-constexpr int FR = 160;                       // rows per workgroup
+constexpr int FR = 80;                        // rows per workgroup
 constexpr int FD = 256;                       // d_model: K of product 1, N of product 2
 constexpr int FC = 128;                       // hidden columns per chunk
-constexpr int F_XT = FR * FD * 2;             // 81,920 B
-constexpr int F_HT = FR * FC * 2;             // 40,960 B
-constexpr int F_LDS = F_XT + 2 * F_HT;        // 163,840 B = the whole LDS of a CU
+constexpr int F_XT = FR * FD * 2;             // 40,960 B
+constexpr int F_HT = FR * FC * 2;             // 20,480 B
+constexpr int F_LDS = F_XT + 2 * F_HT;        // 81,920 B = half the LDS of a CU
 constexpr int F_TP = 68;                      // fp32 image pitch of the final epilogue (floats)
 
 template <typename T>
 struct FfnArgs {
   const T* A; const T* W1; const T* W2; T* H; T* C; const float* bias1; const float* bias2; const T* gate; const T* residual;
+  const unsigned long long* bits_in; unsigned long long* bits_out;
   const eg_step_state* st;
   long long lda, ldh, ldc, ldg, ldr;
-  int M, F, ldw1, ldw2, relu, res_in_lds;
+  int M, F, relu, res_in_lds;
   DropCfg dh, dc1, dc2;
   float gate_scale;
 };
@@ -54,43 +63,47 @@ template <typename T> __device__ __forceinline__ u32x2 f_pack4(const float v[4])
   return o;
 }
 
-template <typename T, int GATE>
-__global__ __launch_bounds__(512, 2) void ffn_chain_kernel(FfnArgs<T> p) {
+template <typename T, int GATE, int BOUT>
+__global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   typedef typename H16<T>::frag frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const xt = smem;
   char* const hb = smem + F_XT;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave = column group
   const int l15 = lane & 15, g4 = lane >> 4;
   const int m0 = blockIdx.x * FR;
   const int nch = p.F / FC;
 
   // ---- A tile: instruction q moves rows 2q, 2q+1 (lane -> row half lane/32, LDS chunk position lane%32 holding global chunk
-  //      pos ^ (row & 7)); wave w issues q = w, w+8, .. (10 each) ----
+  //      pos ^ (row & 7)); wave w issues q = w, w+4, .. (10 each) ----
   {
     const int half = lane >> 5, pos = lane & 31;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-      const int q = wave + 8 * i;
+      const int q = wn + 4 * i;
       const int r = 2 * q + half;
       const int row = min(m0 + r, p.M - 1);
       fdma16((const char*)(p.A + (size_t)row * (size_t)p.lda) + ((pos ^ (r & 7)) << 4), xt + q * 1024);
     }
   }
 
-  // ---- weight fragment streams (global -> registers).  A-operand rows: W1 row = hidden unit, W2 row = output column ----
-  const T* const w1p = p.W1 + (size_t)(32 * wn + l15) * (size_t)p.ldw1 + 8 * g4;   // + (128 c + 16 j) * ldw1 + 32 s
-  const T* const w2p = p.W2 + (size_t)(64 * wn + l15) * (size_t)p.ldw2 + 8 * g4;   // + 16 j * ldw2 + 128 c + 32 s
+  // ---- weight fragment streams (global -> registers): the weights arrive in FRAGMENT ORDER (eg_pack_table modes 3-6), so a
+  //      fragment load is one contiguous 1-KB read per wave.  (Row-major weights cost 64 L1 tag look-ups per load -- 16 rows x
+  //      64 B per quarter wave -- and made the launch tag-rate-bound: 98 us against 72 us for the two launches it replaces.) ----
+  const T* const w1p = p.W1 + (size_t)wn * (8 * 2 * 512) + lane * 8;      // + c * (4*8*2*512) + (s * 2 + j) * 512
+  const T* const w2p = p.W2 + (size_t)wn * (4 * 4 * 512) + lane * 8;      // + c * (4*4*4*512) + (s * 4 + j) * 512
+  // Rolling rings, four (W1) / two (W2) k-steps ahead of their MFMAs and running on across chunk boundaries.  (Requesting a
+  // whole chunk's fragments one phase ahead -- 16 + 16 live fragments -- was built: 67-88 spilled registers; the 256-register
+  // budget of two waves per SIMD is spent on the 5 x 4 + 5 x 2 accumulator tiles.)
   frag w1r[4][2], w2r[2][4];
   auto req_w1 = [&](int c, int s, int slot) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) w1r[slot][j] = *(const frag*)(w1p + (size_t)(FC * c + 16 * j) * (size_t)p.ldw1 + 32 * s);
+    for (int j = 0; j < 2; ++j) w1r[slot][j] = *(const frag*)(w1p + (size_t)c * (4 * 8 * 2 * 512) + (s * 2 + j) * 512);
   };
   auto req_w2 = [&](int c, int s, int slot) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w2r[slot][j] = *(const frag*)(w2p + (size_t)(16 * j) * (size_t)p.ldw2 + FC * c + 32 * s);
+    for (int j = 0; j < 4; ++j) w2r[slot][j] = *(const frag*)(w2p + (size_t)c * (4 * 4 * 4 * 512) + (s * 4 + j) * 512);
   };
 #pragma unroll
   for (int s = 0; s < 4; ++s) req_w1(0, s, s);
@@ -106,10 +119,33 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   uint32_t seed_lo = 0, seed_hi = 0;
   if (p.dh.thresh | p.dc1.thresh | p.dc2.thresh) { seed_lo = p.st->seed_lo; seed_hi = p.st->seed_hi; }
 
+  // ---- weights into the Infinity Cache: in a training step a launch finds its 1 MB of weights in HBM (written a whole step
+  //      earlier), and because all workgroups walk the chunks in lock-step each chunk's first touch stalled every one of them
+  //      (74 us against 62 us when a replayed launch finds them cached).  So every workgroup touches its 1/grid share of ALL
+  //      chunks' 128-B lines here, where the wave waits for its HBM-resident A rows anyway: by the time chunk 1 is needed the
+  //      lines sit in the memory-side cache, one XCD's L2 miss away. ----
+  uint32_t touched = 0;
+  if (wn < 2) {
+    const char* wb = (const char*)(wn == 0 ? p.W1 : p.W2);
+    const int lines = p.F * FD * 2 / 128;                    // per matrix
+    const int per = (lines + gridDim.x - 1) / gridDim.x;
+    for (int t = lane; t < per; t += 64) {
+      const int g = blockIdx.x * per + t;
+      if (g < lines) touched += *(const uint32_t*)(wb + (size_t)g * 128);
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's part of the A tile has landed (and the first fragments)
+  asm volatile("" :: "v"(touched));
   __syncthreads();                                           // ... and everybody else's
 
-  const int rbase = 80 * wm + l15;                           // row of tile i within the workgroup: rbase + 16 i
+  // gate bit words: [workgroup][chunk][wave][lane]
+  const unsigned long long* const bits_p = p.bits_in ? p.bits_in + ((size_t)blockIdx.x * nch * 4 + wn) * 64 + lane : nullptr;
+  unsigned long long gnext0 = 0, gnext1 = 0;
+  if (GATE == 2) {
+    gnext0 = bits_p[0];
+    if (nch > 1) gnext1 = bits_p[256];
+  }
+  const int rbase = l15;                                     // row of tile i within the workgroup: rbase + 16 i
   const int sw7 = l15 & 7;
 
   for (int c = 0; c < nch; ++c) {
@@ -124,8 +160,9 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(FfnArgs<T> p) {
       for (int q = 0; q < 4; ++q) b1[j][q] = 0.f;
       if (p.bias1) load4(p.bias1 + f0 + 16 * j, b1[j]);
     }
+
     u32x2 gt[5][2];
-    if (GATE) {
+    if (GATE == 1) {
       int rb = rbase;
       asm volatile("" : "+v"(rb));                             // addresses are recomputed per chunk, not kept (and spilled) across the loop
 #pragma unroll
@@ -134,6 +171,12 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(FfnArgs<T> p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) gt[i][j] = *(const u32x2*)(p.gate + (size_t)m * (size_t)p.ldg + f0 + 16 * j);
       }
+    }
+    unsigned long long gbits = 0, obits = 0;
+    if (GATE == 2) {                                           // this chunk's word was requested two chunks ago
+      gbits = gnext0;
+      gnext0 = gnext1;
+      if (c + 2 < nch) gnext1 = bits_p[(size_t)(c + 2) * 256];
     }
 
     // ---- product 1: acc1[i][j] = sum_k W1[hidden][k] * A[row][k] ----
@@ -151,7 +194,6 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(FfnArgs<T> p) {
       for (int i = 0; i < 5; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc1[i][j] = H16<T>::mfma(w1r[s & 3][j], xf[i], acc1[i][j]);
-      // the ring slot just consumed is refilled four k-steps ahead (running on into the next chunk)
       if (s < 4) req_w1(c, s + 4, s & 3);
       else if (c + 1 < nch) req_w1(c + 1, s - 4, s & 3);
     }
@@ -169,17 +211,29 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(FfnArgs<T> p) {
           v[q] = acc1[i][j][q] + b1[j][q];
           if (p.relu) v[q] = fmaxf(v[q], 0.f);
         }
-        if (GATE) {
+        if (GATE == 1) {
           float gv[4];
           load4((const T*)&gt[i][j], gv);
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = gv[q] > 0.f ? v[q] * p.gate_scale : 0.f;
         }
+        if (GATE == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = ((gbits >> (4 * (2 * i + j) + q)) & 1ull) ? v[q] * p.gate_scale : 0.f;
+        }
         eg_dropout_run<4>(v, p.dh, seed_lo, seed_hi, m * (uint32_t)p.F + (uint32_t)(f0 + 16 * j));
         const int hcol = 32 * wn + 16 * j + 4 * g4;            // column within the chunk
-        *(u32x2*)(hc + r * 256 + (((hcol >> 3) ^ sw7) << 4) + ((hcol & 4) << 1)) = f_pack4<T>(v);
+        const u32x2 pk = f_pack4<T>(v);
+        *(u32x2*)(hc + r * 256 + (((hcol >> 3) ^ sw7) << 4) + ((hcol & 4) << 1)) = pk;
+        if (BOUT) {                                            // "stored value > 0", taken from the stored 16-bit patterns
+          const uint32_t lo = pk[0], hi = pk[1];
+          const uint32_t b4 = ((lo & 0x7fffu) && !(lo & 0x8000u) ? 1u : 0u) | ((lo & 0x7fff0000u) && !(lo & 0x80000000u) ? 2u : 0u) |
+                              ((hi & 0x7fffu) && !(hi & 0x8000u) ? 4u : 0u) | ((hi & 0x7fff0000u) && !(hi & 0x80000000u) ? 8u : 0u);
+          obits |= (unsigned long long)b4 << (4 * (2 * i + j));
+        }
       }
     }
+    if (BOUT) p.bits_out[((size_t)blockIdx.x * nch + c) * 256 + wn * 64 + lane] = obits;
     __syncthreads();        // chunk c is complete in LDS; nobody reads buffer (c+1)&1 (chunk c-1) any more
 
     // ---- the stored result: whole 256-B row segments of the chunk, 16 B per thread ----
@@ -187,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(FfnArgs<T> p) {
     asm volatile("" : "+v"(tq));                               // (same: no loop-invariant address registers)
 #pragma unroll
     for (int ps = 0; ps < 5; ++ps) {
-      const int r = 32 * ps + tq, ch = tid & 15;
+      const int r = 16 * ps + tq, ch = tid & 15;
       const u32x4 o = *(const u32x4*)(hc + r * 256 + ((ch ^ (r & 7)) << 4));
       if (m0 + r < p.M) *(u32x4*)(p.H + (size_t)(m0 + r) * (size_t)p.ldh + FC * c + 8 * ch) = o;
     }
@@ -209,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   __syncthreads();          // every wave has left the chunk buffers: they become the fp32 image of the final epilogue
 
   // ---- epilogue 2: per 16-row tile through a wave-private fp32 image [16][68]; a lane then owns 16 consecutive columns of a row ----
-  float* timg = (float*)(hb + wave * (16 * F_TP * 4));
+  float* timg = (float*)(hb + wn * (16 * F_TP * 4));
   const int er = lane >> 2, ec = lane & 3;
   const int n = 64 * wn + 16 * ec;
   float bv[16];
@@ -221,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   for (int i = 0; i < 5; ++i) {
     eraw[i][0] = (u32x4){0u, 0u, 0u, 0u};
     eraw[i][1] = (u32x4){0u, 0u, 0u, 0u};
-    const int r = 80 * wm + 16 * i + er;
+    const int r = 16 * i + er;
     if (p.res_in_lds) {
       eraw[i][0] = *(const u32x4*)(xt + r * 512 + ((((n >> 3)) ^ (r & 7)) << 4));
       eraw[i][1] = *(const u32x4*)(xt + r * 512 + ((((n >> 3) + 1) ^ (r & 7)) << 4));
@@ -233,10 +287,10 @@ __global__ __launch_bounds__(512, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   }
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
-    const int m = m0 + 80 * wm + 16 * i + er;
+    const int m = m0 + 16 * i + er;
 #pragma unroll
     for (int j = 0; j < 4; ++j) *(f32x4*)(timg + l15 * F_TP + 16 * j + 4 * g4) = acc2[i][j];
-    if (m0 + 80 * wm + 16 * i >= p.M) break;                 // wave-uniform: tiles wholly beyond M
+    if (m0 + 16 * i >= p.M) break;                 // wave-uniform: tiles wholly beyond M
     float v[16];
     load8(timg + er * F_TP + 16 * ec, v);
     load8(timg + er * F_TP + 16 * ec + 8, v + 8);
@@ -270,26 +324,27 @@ template <typename T>
 static int ffn_launch(const eg_ffn_desc* d, hipStream_t s) {
   FfnArgs<T> p;
   p.A = (const T*)d->A; p.W1 = (const T*)d->W1; p.W2 = (const T*)d->W2; p.H = (T*)d->H; p.C = (T*)d->C;
+  p.bits_in = (const unsigned long long*)d->gate_bits_in; p.bits_out = (unsigned long long*)d->gate_bits_out;
   p.bias1 = d->bias1; p.bias2 = d->bias2; p.gate = (const T*)d->gate; p.residual = (const T*)d->residual; p.st = d->state;
   p.lda = d->lda; p.ldh = d->ldh; p.ldc = d->ldc; p.ldg = d->ldg; p.ldr = d->ldr;
-  p.M = d->M; p.F = d->F; p.ldw1 = FD; p.ldw2 = d->F;
+  p.M = d->M; p.F = d->F;
   p.relu = d->act1 == EG_ACT_RELU;
   p.res_in_lds = d->residual && d->residual == d->A && d->ldr == d->lda;
   p.dh = make_drop(d->drop_h_p, d->drop_h_site);
   p.dc1 = make_drop(d->drop_c1_p, d->drop_c1_site);
   p.dc2 = make_drop(d->drop_c2_p, d->drop_c2_site);
   p.gate_scale = d->gate_scale == 0.f ? 1.0f : d->gate_scale;
-  const dim3 grid((d->M + FR - 1) / FR), blk(512);
-#define FFN_LAUNCH(G_)                                                                                                 \
+  const dim3 grid((d->M + FR - 1) / FR);
+#define FFN_LAUNCH(G_, B_)                                                                                                 \
   do {                                                                                                                 \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      (void)hipFuncSetAttribute((const void*)ffn_chain_kernel<T, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS); \
+      (void)hipFuncSetAttribute((const void*)ffn_chain_kernel<T, G_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS); \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((ffn_chain_kernel<T, G_>), grid, blk, F_LDS, s, p);                                             \
+    hipLaunchKernelGGL((ffn_chain_kernel<T, G_, B_>), grid, dim3(256), F_LDS, s, p);                                                        \
   } while (0)
-  if (d->gate) FFN_LAUNCH(1); else FFN_LAUNCH(0);
+  if (d->gate_bits_in) FFN_LAUNCH(2, 0); else if (d->gate) FFN_LAUNCH(1, 0); else if (d->gate_bits_out) FFN_LAUNCH(0, 1); else FFN_LAUNCH(0, 0);
 #undef FFN_LAUNCH
   EG_LAUNCH_CHECK("ffn_chain");
   return 0;
@@ -305,6 +360,8 @@ extern "C" int eg_ffn_chain(const eg_ffn_desc* d, void* stream) {
   EG_CHECK(d->lda >= FD && d->ldc >= FD && d->ldh >= d->F && d->lda % 8 == 0 && d->ldc % 8 == 0 && d->ldh % 8 == 0,
            "eg_ffn_chain: row strides must be 16-B multiples covering the rows");
   EG_CHECK(!d->gate || (d->ldg >= d->F && d->ldg % 4 == 0), "eg_ffn_chain: gate stride");
+  EG_CHECK(!(d->gate_bits_out && (d->gate_bits_in || d->gate)), "eg_ffn_chain: a launch either writes gate bits or applies a gate");
+  EG_CHECK(((uintptr_t)d->gate_bits_in | (uintptr_t)d->gate_bits_out) % 8 == 0, "eg_ffn_chain: gate bit words must be 8-B aligned");
   EG_CHECK(!d->residual || (d->ldr >= FD && d->ldr % 8 == 0), "eg_ffn_chain: residual stride");
   EG_CHECK((long long)d->M * d->F < (1ll << 32), "eg_ffn_chain: M*F exceeds the 32-bit dropout index");
   const float ps[3] = {d->drop_h_p, d->drop_c1_p, d->drop_c2_p};
@@ -314,4 +371,9 @@ extern "C" int eg_ffn_chain(const eg_ffn_desc* d, void* stream) {
             (uintptr_t)d->residual) % 16 == 0, "eg_ffn_chain: operands must be 16-B aligned");
   hipStream_t s = (hipStream_t)stream;
   return d->dtype == EG_F16 ? ffn_launch<f16_t>(d, s) : ffn_launch<bf16_t>(d, s);
+}
+
+extern "C" int64_t eg_ffn_gate_bits_bytes(int M, int F) {
+  if (M <= 0 || F <= 0) return 0;
+  return (int64_t)((M + FR - 1) / FR) * (F / FC) * 256 * 8;
 }

@@ -112,8 +112,9 @@ __global__ void pack_convT_weight_kernel(const float* __restrict__ w, T* __restr
 
 // table-driven parameter staging: ONE launch re-casts / transposes every weight of the model.
 // mode 0: dst[i] = cast(src[i]) over rows*cols contiguous elements; mode 1: dst[c*ldd + r] = cast(src[r*cols + c]);
-// mode 2: like 0 but the destination is fp32 (bias vectors gathered into fused buffers).  Each block handles one
-// 32x32 tile (mode 1) or 1024 elements (modes 0/2); blk0 is the entry's first block.
+// mode 2: like 0 but the destination is fp32 (bias vectors gathered into fused buffers); modes 3-6: eg_ffn_chain's fragment
+// order (16-bit dtypes).  Each block handles one 32x32 tile (mode 1), 1024 elements (modes 0/2) or 2048 elements (modes 3-6);
+// blk0 is the entry's first block.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_table_kernel(const eg_pack_entry* __restrict__ tab, int nent) {
   __shared__ float tile[32][33];
@@ -143,6 +144,32 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const eg_pack_entry* __
     for (int i = ty; i < 32; i += 8) {
       const int c = c0 + i, r = r0 + tx;
       if (c < e.cols && r < e.rows) Elem<T>::st(dst + (size_t)c * e.ldd + r, tile[tx][i]);
+    }
+  } else if (e.mode >= 3 && e.mode <= 6) {
+    // MFMA-fragment order of eg_ffn_chain's weights: destination chunk q (8 elements) is what lane q%64 of a wave loads as
+    // its operand of one v_mfma_f32_16x16x32, so a fragment load is ONE contiguous 1-KB read.  The logical matrix is the source
+    // (modes 3, 5) or its transpose (modes 4, 6); role 1 = [F, 256] (modes 3, 4), role 2 = [256, F] (modes 5, 6).
+    const int q = lb * 256 + threadIdx.x;
+    const bool tr = e.mode == 4 || e.mode == 6;
+    const int lane = q & 63, l15 = lane & 15, g4 = lane >> 4;
+    int n, k0, N, K;
+    if (e.mode <= 4) {                       // role 1: [chunk c][wn][s: 8][j: 2][lane]
+      const int j = (q >> 6) & 1, s8 = (q >> 7) & 7, wn = (q >> 10) & 3, c = q >> 12;
+      n = 128 * c + 32 * wn + 16 * j + l15; k0 = 32 * s8 + 8 * g4;
+      K = 256; N = tr ? e.cols : e.rows;
+    } else {                                 // role 2: [chunk c][wn][s: 4][j: 4][lane]
+      const int j = (q >> 6) & 3, s4 = (q >> 8) & 3, wn = (q >> 10) & 3, c = q >> 12;
+      n = 64 * wn + 16 * j + l15; k0 = 128 * c + 32 * s4 + 8 * g4;
+      N = 256; K = tr ? e.rows : e.cols;
+    }
+    if ((long long)q * 8 < (long long)e.rows * e.cols) {
+      float v[8];
+      if (!tr) load8(src + (size_t)n * K + k0, v);
+      else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(k0 + i) * N + n];
+      }
+      if constexpr (sizeof(T) == 2) store8((T*)e.dst + (size_t)q * 8, v);
     }
   } else {
     const long long n = (long long)e.rows * e.cols;

@@ -150,6 +150,9 @@ class Engine:
         self.probes = {}   # tag -> (start_event, end_event) recorded around that launch
         # LayerNorm forward / backward run in the epilogue of the adjacent N == d_model product (row-complete GEMM tile)
         self.fuse_ln = cfg.d_model == 256 and os.environ.get("EYEGAZE_FUSE_LN", "0") == "1"
+        # feed-forward pair as one launch (csrc/ffn.hip): 16-bit compute dtypes, d_model == 256, d_ff a multiple of 128
+        self.fuse_ffn = (dtype != EG_F32 and cfg.d_model == 256 and cfg.d_ff % 128 == 0 and not self.fuse_ln
+                         and os.environ.get("EYEGAZE_FFN", "1") != "0")
         self.ln_nblk_cap = max(self.LN_BLOCKS, (self.M + 63) // 64)
         if (self.M + 63) // 64 > 2048:
             self.fuse_ln = False      # the scratch partial buffer holds 2048 workgroups
@@ -184,6 +187,9 @@ class Engine:
                 w[f"w1T{l}"] = self._t(d, F)
                 w[f"w2{l}"] = self._t(d, F)
                 w[f"w2T{l}"] = self._t(F, d)
+                if self.fuse_ffn:       # the same four matrices in eg_ffn_chain's MFMA-fragment order (eg_pack_table modes 3-6)
+                    for nm in ("w1f", "w2f", "w2Tf", "w1Tf"):
+                        w[f"{nm}{l}"] = self._t(F * d)
         w["sf"] = self._t(d, 3 * d)
         w["sfT"] = self._t(3 * d, d)
         w["c0"] = self._t(d, 3 * d)
@@ -205,6 +211,8 @@ class Engine:
             a[f"st1_{l}"] = self._t(M, 2, dtype=f32)
             a[f"y1_{l}"] = self._t(M, d)
             a[f"hff{l}"] = self._t(M, F)
+            if self.fuse_ffn:           # ReLU / dropout gate of the hidden rows, one bit per element (forward -> backward)
+                a[f"gbits{l}"] = torch.zeros(L.gate_bits_bytes(M, F) // 8, device=self.device, dtype=torch.int64)
             a[f"r2_{l}"] = self._t(M, d)
             a[f"st2_{l}"] = self._t(M, 2, dtype=f32)
             a[f"x{l + 1}"] = self._t(M, d)
@@ -324,6 +332,33 @@ class Engine:
         if probe:
             probe[0].record(torch.cuda.current_stream(self.device))
         call("eg_gemm_nt", C.byref(dsc), self.stream)
+        if probe:
+            probe[1].record(torch.cuda.current_stream(self.device))
+
+    def ffn(self, A, W1f, W2f, H, Cout, M, F, *, bias1=0, bias2=0, act1=0, residual=0, gate=0, bits_out=0, bits_in=0,
+            drop_h=(0.0, 0), drop_c1=(0.0, 0), drop_c2=(0.0, 0), gate_scale=1.0):
+        """eg_ffn_chain: H = epi1(A W1^T), C = epi2(H W2^T) in one launch (weights in fragment order)."""
+        d = self.cfg.d_model
+        dsc = L.FfnDesc()
+        dsc.A, dsc.W1, dsc.W2, dsc.H, dsc.C = A, W1f, W2f, H, Cout
+        dsc.bias1, dsc.bias2, dsc.gate, dsc.residual = bias1 or None, bias2 or None, gate or None, residual or None
+        dsc.gate_bits_out, dsc.gate_bits_in = bits_out or None, bits_in or None
+        dsc.state = self.st_ptr
+        dsc.lda, dsc.ldh, dsc.ldc, dsc.ldg, dsc.ldr = d, F, d, F, d
+        dsc.M, dsc.F, dsc.act1, dsc.dtype = M, F, act1, self.dtype
+        dsc.drop_h_p, dsc.drop_h_site = drop_h
+        dsc.drop_c1_p, dsc.drop_c1_site = drop_c1
+        dsc.drop_c2_p, dsc.drop_c2_site = drop_c2
+        dsc.gate_scale = gate_scale
+        probe = None
+        if self.probe_all is not None:      # bench.py: timed like the eg_gemm_nt launches, as its own kernel (route 4)
+            probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            es = self.es
+            nbytes = es * (M * d * (2 + (1 if residual and residual != A else 0)) + M * F * (1 + (1 if gate else 0)) + 2 * F * d) \
+                + (M * F // 8 if (bits_out or bits_in) else 0) + 4 * (F + d)
+            self.probe_all.append((probe[0], probe[1], 4.0 * M * F * d, float(nbytes), (M, F, d), 4))
+            probe[0].record(torch.cuda.current_stream(self.device))
+        call("eg_ffn_chain", C.byref(dsc), self.stream)
         if probe:
             probe[1].record(torch.cuda.current_stream(self.device))
 
@@ -614,6 +649,11 @@ class Engine:
         if self._recording:
             self._plan.append((src, dst, R, Cc, ldd, 1))
 
+    def p_frag(self, src, dst, R, Cc, mode):
+        """eg_ffn_chain's fragment order of the fp32 parameter src [R, Cc] (eg_pack_table modes 3-6)."""
+        if self._recording:
+            self._plan.append((src, dst, R, Cc, 0, mode))
+
     def pack_params(self):
         key = (self.fp.flat.data_ptr(), self.stream)
         if getattr(self, "_plan_key", None) != key[0]:
@@ -623,7 +663,8 @@ class Engine:
             ents = (L.PackEntry * len(self._plan))()
             blk = 0
             for e, (src, dst, R, Cc, ldd, mode) in zip(ents, self._plan):
-                nb = ((R + 31) // 32) * ((Cc + 31) // 32) if mode == 1 else (R * Cc + 1023) // 1024
+                nb = (((R + 31) // 32) * ((Cc + 31) // 32) if mode == 1 else (R * Cc) // 2048 if mode >= 3 else
+                      (R * Cc + 1023) // 1024)
                 e.src, e.dst, e.rows, e.cols, e.ldd, e.mode, e.blk0, e.nblk = src, dst, R, Cc, ldd, mode, blk, nb
                 blk += nb
             raw = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8)
@@ -657,6 +698,11 @@ class Engine:
             self.p_transpose(fp.p_ptr(pre + "ffn.linear1.weight"), ptr(w[f"w1T{l}"]), F, d, F)
             self.p_cast(fp.p_ptr(pre + "ffn.linear2.weight"), ptr(w[f"w2{l}"]), d * F)
             self.p_transpose(fp.p_ptr(pre + "ffn.linear2.weight"), ptr(w[f"w2T{l}"]), d, F, d)
+            if self.fuse_ffn:
+                self.p_frag(fp.p_ptr(pre + "ffn.linear1.weight"), ptr(w[f"w1f{l}"]), F, d, 3)     # forward product 1
+                self.p_frag(fp.p_ptr(pre + "ffn.linear2.weight"), ptr(w[f"w2f{l}"]), d, F, 5)     # forward product 2
+                self.p_frag(fp.p_ptr(pre + "ffn.linear2.weight"), ptr(w[f"w2Tf{l}"]), d, F, 4)    # backward product 1 = linear2^T
+                self.p_frag(fp.p_ptr(pre + "ffn.linear1.weight"), ptr(w[f"w1Tf{l}"]), F, d, 6)    # backward product 2 = linear1^T
         if cfg.use_cross_attention:
             attn_pack("cross_attn.cross_attn.", "x")
         self.p_cast(fp.p_ptr("symmetric_fusion.proj.weight"), ptr(w["sf"]), 3 * d * d)
@@ -710,11 +756,17 @@ class Engine:
                       drop1=(p, sites["drop1"]), residual=ptr(x), ln=self._ln_f(pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"]))
             if not self.fuse_ln:
                 self.ln_fwd(a[f"r1_{l}"], pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"])
-            self.gemm(ptr(a[f"y1_{l}"]), ptr(w[f"w1{l}"]), ptr(a[f"hff{l}"]), M, F, d, bias=fp.p_ptr(pre + "ffn.linear1.bias"),
-                      act=L.ACT_RELU, drop1=(p, sites["ffn_a"]))
-            self.gemm(ptr(a[f"hff{l}"]), ptr(w[f"w2{l}"]), ptr(a[f"r2_{l}"]), M, d, F, bias=fp.p_ptr(pre + "ffn.linear2.bias"),
-                      drop1=(p, sites["ffn_b"]), drop2=(p, sites["drop2"]), residual=ptr(a[f"y1_{l}"]),
-                      ln=self._ln_f(pre + "ln2", a[f"x{l + 1}"], a[f"st2_{l}"]))
+            if self.fuse_ffn:       # linear1 -> ReLU -> dropout -> linear2 -> dropout x2 -> + residual in one launch (A:272, A:294)
+                self.ffn(ptr(a[f"y1_{l}"]), ptr(w[f"w1f{l}"]), ptr(w[f"w2f{l}"]), ptr(a[f"hff{l}"]), ptr(a[f"r2_{l}"]), M, F,
+                         bias1=fp.p_ptr(pre + "ffn.linear1.bias"), bias2=fp.p_ptr(pre + "ffn.linear2.bias"), act1=L.ACT_RELU,
+                         residual=ptr(a[f"y1_{l}"]), drop_h=(p, sites["ffn_a"]), drop_c1=(p, sites["ffn_b"]),
+                         drop_c2=(p, sites["drop2"]), bits_out=ptr(a[f"gbits{l}"]))
+            else:
+                self.gemm(ptr(a[f"y1_{l}"]), ptr(w[f"w1{l}"]), ptr(a[f"hff{l}"]), M, F, d, bias=fp.p_ptr(pre + "ffn.linear1.bias"),
+                          act=L.ACT_RELU, drop1=(p, sites["ffn_a"]))
+                self.gemm(ptr(a[f"hff{l}"]), ptr(w[f"w2{l}"]), ptr(a[f"r2_{l}"]), M, d, F, bias=fp.p_ptr(pre + "ffn.linear2.bias"),
+                          drop1=(p, sites["ffn_b"]), drop2=(p, sites["drop2"]), residual=ptr(a[f"y1_{l}"]),
+                          ln=self._ln_f(pre + "ln2", a[f"x{l + 1}"], a[f"st2_{l}"]))
             if not self.fuse_ln:
                 self.ln_fwd(a[f"r2_{l}"], pre + "ln2", a[f"x{l + 1}"], a[f"st2_{l}"])
         Lr = cfg.num_layers
@@ -862,10 +914,21 @@ class Engine:
             dr = g["dr"] if has_drop else dYf
             if not grouped:
                 self.wgrad(ptr(dYf), ptr(a[f"hff{l}"]), 0, M, d, F, linear=[pre + "ffn.linear2"])
-            self.gemm(ptr(dYf), ptr(w[f"w2T{l}"]), ptr(dh), M, F, d, gate=ptr(a[f"hff{l}"]), gate_scale=sc)
+            if self.fuse_ffn:
+                # dH = gate(dY W2) (stored: the weight gradients read it) and dy1 = dH W1 + dr in one launch; the gate is the
+                # bit image the forward launch of this layer left
+                self.ffn(ptr(dYf), ptr(w[f"w2Tf{l}"]), ptr(w[f"w1Tf{l}"]), ptr(dh), ptr(g["dy1"]), M, F, residual=ptr(dr),
+                         bits_in=ptr(a[f"gbits{l}"]), gate_scale=sc)
+            else:
+                self.gemm(ptr(dYf), ptr(w[f"w2T{l}"]), ptr(dh), M, F, d, gate=ptr(a[f"hff{l}"]), gate_scale=sc)
             if not grouped:
                 self.wgrad(ptr(dh), ptr(a[f"y1_{l}"]), 0, M, F, d, linear=[pre + "ffn.linear1"])
-            if fuse:
+            if self.fuse_ffn:
+                if has_drop:
+                    self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", g["dr"], dYo, d1=(p, sites["drop1"]), slot=s1)
+                else:
+                    self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", dYo, None, slot=s1)
+            elif fuse:
                 # FFN-1 backward-data + residual gradient, with ln1's backward in the epilogue (dy1 is never written)
                 spec = (self._ln_b(pre + "ln1", a[f"r1_{l}"], a[f"st1_{l}"], g["dr"], dYo, d1=(p, sites["drop1"]), slot=s1)
                         if has_drop else self._ln_b(pre + "ln1", a[f"r1_{l}"], a[f"st1_{l}"], dYo, None, slot=s1))

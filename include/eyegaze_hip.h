@@ -102,7 +102,9 @@ int eg_window_normalize(const float* raw, float* eeg1, float* eeg2, int N, int C
  */
 /* eg_pack_table: all of the above casts / transposes of one model in ONE launch.  `table` is a DEVICE array; entry i owns
  * blocks [blk0, blk0 + nblk): mode 0 cast (1024 elements per block), 1 transpose-cast (one 32x32 tile per block),
- * 2 fp32 copy (fused bias vectors).  src / dst are absolute device addresses. */
+ * 2 fp32 copy (fused bias vectors); 3-6 eg_ffn_chain's MFMA-fragment order of a 16-bit weight (2048 elements per block; the
+ * source is fp32 [rows, cols]): 3 role 1 = src [F, 256], 4 role 1 = src^T (src [256, F]), 5 role 2 = src [256, F],
+ * 6 role 2 = src^T (src [F, 256]); see eg_ffn_desc.  src / dst are absolute device addresses. */
 typedef struct eg_pack_entry {
   uint64_t src, dst;
   int32_t rows, cols, ldd, mode, blk0, nblk;
@@ -177,13 +179,18 @@ int eg_gemm_nt_route(const eg_gemm_desc* d);
  * ------------------------------------------------------------------------------------------- */
 typedef struct eg_ffn_desc {
   const void* A;        /* [M, 256], row stride lda */
-  const void* W1;       /* [F, 256] row-major */
-  const void* W2;       /* [256, F] row-major */
+  const void* W1;       /* [F, 256] in fragment order: eg_pack_table mode 3 (or 4 from the transposed parameter) */
+  const void* W2;       /* [256, F] in fragment order: eg_pack_table mode 5 (or 6) */
   void* H;              /* [M, F], row stride ldh */
   void* C;              /* [M, 256], row stride ldc */
   const float* bias1;   /* [F] or NULL */
   const float* bias2;   /* [256] or NULL */
   const void* gate;     /* [M, F], row stride ldg, or NULL */
+  /* The same gate as one bit per element ("stored H value > 0"), written by a launch with gate_bits_out set and read by a
+   * later launch with gate_bits_in set (then `gate` is not read).  Opaque, in the kernel's own lane order: valid only between
+   * launches with equal M and F; size eg_ffn_gate_bits_bytes(M, F). */
+  void* gate_bits_out;
+  const void* gate_bits_in;
   const void* residual; /* [M, 256], row stride ldr, or NULL; may alias A (then it is taken from the on-chip A tile) */
   const eg_step_state* state;
   int64_t lda, ldh, ldc, ldg, ldr;
@@ -193,6 +200,7 @@ typedef struct eg_ffn_desc {
   float gate_scale;
 } eg_ffn_desc;
 int eg_ffn_chain(const eg_ffn_desc* d, void* stream);
+int64_t eg_ffn_gate_bits_bytes(int M, int F);
 
 /* ---------------------------------------------------------------------------------------------
  * eg_gemm_tn — weight-gradient product  dW[N,K] = sum_m dY[m,n] * X[m,k]  (fp32 result)

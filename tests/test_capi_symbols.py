@@ -11,7 +11,7 @@ REPO = Path(__file__).resolve().parent.parent
 def declared_symbols():
     text = (REPO / "include" / "eyegaze_hip.h").read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(eg_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t|const char\*)\s+(eg_\w+)\s*\(", text)))
 
 
 def test_library_builds_and_exports_every_declared_symbol():
@@ -31,10 +31,11 @@ def test_library_builds_and_exports_every_declared_symbol():
 def test_binding_covers_the_header():
     from eyegaze_multimodal_amd import _lib
     names = set(declared_symbols())
-    bound = set(_lib.SIGNATURES) | {"eg_abi_version", "eg_last_error"}
+    bound = set(_lib.SIGNATURES) | {"eg_abi_version", "eg_last_error", "eg_ffn_gate_bits_bytes"}   # (the last: _lib.gate_bits_bytes)
     assert names <= bound, sorted(names - bound)
     exported = _lib.exported_symbols()
-    assert all(exported[n] for n in names), [n for n in names if not exported[n]]
+    assert all(exported.get(n, hasattr(_lib.lib(), n)) for n in names), [n for n in names if not exported.get(n)]
+    assert _lib.gate_bits_bytes(33280, 1024) == 416 * 8 * 256 * 8      # host-only size helper of eg_ffn_chain's gate bit image
 
 
 def test_host_side_argument_checks_run_without_a_gpu():
