@@ -8,6 +8,7 @@
 // Backward recomputes P from the saved log-sum-exp (flash style): pass A (key rows / query lanes) gives dQ,
 // pass B (query rows / key lanes) gives dK and dV; delta = rowsum(dO * O).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -306,12 +307,27 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
             const f32x4 l4 = *(const f32x4*)(lsel + qt * 16 + 4 * g);
             const f32x4 d4 = *(const f32x4*)(dl + qt * 16 + 4 * g);
             const uint32_t Sp2b = (uint32_t)((S + 1) & ~1);
+            // One hash serves the elements (q, key) and (q, key ^ 1), which here sit in NEIGHBOURING LANES: a lane hashes two
+            // of its four query rows (even keys rows 0-1, odd keys rows 2-3) and takes the other two from lane ^ 1.
+            uint32_t hh[4] = {0u, 0u, 0u, 0u};
+            if (dc.thresh) {
+              const uint32_t odd = (uint32_t)key & 1u;
+              const uint32_t ia = (headidx + (uint32_t)(qt * 16 + 4 * g) + 2u * odd) * Sp2b + (uint32_t)key;
+              const uint32_t ha = eg_hash(seed_lo, seed_hi, dc.site, ia >> 1);
+              const uint32_t hb = eg_hash(seed_lo, seed_hi, dc.site, (ia + Sp2b) >> 1);
+              const uint32_t pa = (uint32_t)__shfl_xor((int)ha, 1, 64), pb = (uint32_t)__shfl_xor((int)hb, 1, 64);
+              hh[0] = odd ? pa : ha; hh[1] = odd ? pb : hb;
+              hh[2] = odd ? ha : pa; hh[3] = odd ? hb : pb;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int qq = qt * 16 + 4 * g + r;
               const float p = (key < S && qq < S) ? __expf(s[r] * kScale - l4[r]) : 0.f;
               float m = 1.0f;
-              if (dc.thresh) m = eg_dropout(1.0f, dc, seed_lo, seed_hi, (headidx + (uint32_t)qq) * Sp2b + (uint32_t)key);
+              if (dc.thresh) {
+                const uint32_t half = ((uint32_t)key & 1u) ? (hh[r] >> 16) : (hh[r] & 0xFFFFu);
+                m = half >= dc.thresh ? dc.scale : 0.0f;
+              }
               pd2[h2][r] = p * m;
               ds2[h2][r] = p * (dp[r] * m - d4[r]);
             }
@@ -336,6 +352,203 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
         T* row = dqkv + ((long long)bk * S + key) * ld + h * 32 + 16 * dt + 4 * g;
         store4(row + D, a);
         store4(row + 2 * D, c);
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Single-sweep backward (S <= 128): every 16 x 16 block of P / dS is computed ONCE.
+// The two-pass kernel above evaluates exp and the dropout hash of each block twice (pass B in the transposed layout, with one
+// hash per element instead of one per pair) and is VALU-bound on exactly that.  Here a wave takes alternate query tiles; per
+// block it forms, in the key-rows / query-lanes layout, P*mask and dS, feeds dS straight into the dQ MFMA (as pass A does),
+// and TRANSPOSES both through a 4-KB wave-private LDS image -- written as 8-B row pieces, read back with ds_read_b64_tr_b16
+// as the B operands (key lanes, query k-slots) of the dV / dK MFMAs.  A wave's image holds one query tile in its half of the
+// 32 k-slots; the other half stays zero (a wave's tiles all have the same parity), so the A operands -- the transposed dO / Q
+// fragments of the tile PAIR -- need no masking.  dK / dV accumulate in registers over the wave's query tiles (16 registers
+// per key tile); the two waves of a head exchange one partial each through LDS (role 0 finishes dK, role 1 dV): a fixed order,
+// so results stay bit-reproducible.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int SP>
+__global__ __launch_bounds__(256) void attn_bwd1_kernel(const T* __restrict__ qkv, const T* __restrict__ ctx,
+                                                        const T* __restrict__ dctx, const float* __restrict__ lse,
+                                                        T* __restrict__ dqkv, int NB, int S, int H, int kv_shift,
+                                                        DropCfg dc, const eg_step_state* st) {
+  constexpr int NKT = SP / 16;
+  constexpr int IMG = SP * 64;
+  constexpr int SCR = 2 * 32 * 64;                            // one wave's P and dS images: [32 query slots][32 keys]
+  constexpr int WB = 4 * IMG + 2 * SP * 4 + 2 * SCR;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, role = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  int pid = blockIdx.x * 2 + (wave >> 1);
+  const bool valid = pid < NB * H;
+  if (!valid) pid = NB * H - 1;
+  const int b = pid / H, h = pid % H;
+  const int bk = (b + kv_shift) % NB;
+  const int D = H * 32;
+  const long long ld = 3ll * D;
+  const T* qbase = qkv + (long long)b * S * ld + h * 32;
+  const T* kbase = qkv + (long long)bk * S * ld + D + h * 32;
+  const T* vbase = kbase + D;
+  const T* dobase = dctx + (long long)b * S * D + h * 32;
+  const T* obase = ctx + (long long)b * S * D + h * 32;
+  char* base = smem + (wave >> 1) * WB;
+  char* qimg = base;
+  char* kimg = base + IMG;
+  char* vimg = base + 2 * IMG;
+  char* doimg = base + 3 * IMG;
+  float* lsel = (float*)(base + 4 * IMG);
+  float* dl = lsel + SP;
+  char* pimg = base + 4 * IMG + 2 * SP * 4 + role * SCR;
+  char* simg = pimg + 32 * 64;
+  stage_rows<T>(qimg, qbase, ld, S, SP, lane + 64 * role, 128);
+  stage_rows<T>(kimg, kbase, ld, S, SP, lane + 64 * role, 128);
+  stage_rows<T>(vimg, vbase, ld, S, SP, lane + 64 * role, 128);
+  stage_rows<T>(doimg, dobase, D, S, SP, lane + 64 * role, 128);
+  for (int i = lane; i < SCR / 16; i += 64) *(u32x4*)(pimg + i * 16) = (u32x4){0u, 0u, 0u, 0u};
+  for (int q = lane + 64 * role; q < SP; q += 128) {
+    float l = 0.f, dsum = 0.f;
+    if (q < S) {
+      l = lse[((long long)b * H + h) * S + q];
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        float a[8], o[8];
+        load8(dobase + (long long)q * D + c4 * 8, a);
+        load8(obase + (long long)q * D + c4 * 8, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += a[e] * o[e];
+      }
+    }
+    lsel[q] = l;
+    dl[q] = dsum;
+  }
+  const int nkt = (S + 15) >> 4;
+  uint32_t seed_lo = 0, seed_hi = 0;
+  if (dc.thresh) { seed_lo = st->seed_lo; seed_hi = st->seed_hi; }
+  const uint32_t headidx = (uint32_t)((b * H + h) * S);
+  const uint32_t Sp2 = (uint32_t)((S + 1) & ~1);
+  __syncthreads();
+
+  f32x4 dk[NKT][2], dv[NKT][2];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      dk[kt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dv[kt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  // this wave's 8-B piece of an image row: query slot 16*role + l15, key columns 16*t + 4g .. +3 of the pair
+  const int srow = 16 * role + l15;
+
+  for (int qt = role; qt < nkt; qt += 2) {
+    const int q = qt * 16 + l15;
+    const FR<T> qf = ld_frag_lds_row<T>(qimg, q, g);
+    const FR<T> dof = ld_frag_lds_row<T>(doimg, q, g);
+    const float lq = lsel[q], dq = dl[q];
+    const uint32_t rowidx = (headidx + (uint32_t)q) * Sp2;
+    FR<T> dotr[2], qtr[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      dotr[dt] = ld_frag_lds_tr<T>(doimg, 32 * (qt >> 1), dt, lane);
+      qtr[dt] = ld_frag_lds_tr<T>(qimg, 32 * (qt >> 1), dt, lane);
+    }
+    f32x4 accq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kp = 0; kp < NKT / 2; ++kp) {
+      if (2 * kp < nkt) {
+        f32x4 ds2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int kt = 2 * kp + t;
+          ds2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (kt < nkt) {
+            const FR<T> kfr = ld_frag_lds_row<T>(kimg, kt * 16 + l15, g);
+            const FR<T> vfr = ld_frag_lds_row<T>(vimg, kt * 16 + l15, g);
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 sT = H16<T>::mfma(kfr, qf, z);
+            const f32x4 dpT = H16<T>::mfma(vfr, dof, z);
+            float m[4] = {1.f, 1.f, 1.f, 1.f};
+            eg_dropout_run<4>(m, dc, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g));
+            float pd[4], dsv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = kt * 16 + 4 * g + r;
+              const float p = (key < S && q < S) ? __expf(sT[r] * kScale - lq) : 0.f;
+              pd[r] = p * m[r];
+              dsv[r] = p * (dpT[r] * m[r] - dq);
+              ds2[t][r] = dsv[r];
+            }
+            const int off = img_chunk_off(srow, 2 * t + (g >> 1)) + ((g & 1) << 3);
+            u32x2 pw, sw;
+            pw[0] = H16<T>::pack2(pd[0], pd[1]);  pw[1] = H16<T>::pack2(pd[2], pd[3]);
+            sw[0] = H16<T>::pack2(dsv[0], dsv[1]); sw[1] = H16<T>::pack2(dsv[2], dsv[3]);
+            *(u32x2*)(pimg + off) = pw;
+            *(u32x2*)(simg + off) = sw;
+          }
+        }
+        // dQ: dS is already the B operand (query lanes, key k-slots)
+        const FR<T> dsf = pack_frag<T>(ds2[0], ds2[1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const FR<T> ktr = ld_frag_lds_tr<T>(kimg, 32 * kp, dt, lane);
+          accq[dt] = H16<T>::mfma(ktr, dsf, accq[dt]);
+        }
+        // dV, dK: the transposed blocks (key lanes, query k-slots) come back from the wave's images
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int kt = 2 * kp + t;
+          if (kt < nkt) {
+            const FR<T> pdf = ld_frag_lds_tr<T>(pimg, 0, t, lane);
+            const FR<T> dsT = ld_frag_lds_tr<T>(simg, 0, t, lane);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+              dv[kt][dt] = H16<T>::mfma(dotr[dt], pdf, dv[kt][dt]);
+              dk[kt][dt] = H16<T>::mfma(qtr[dt], dsT, dk[kt][dt]);
+            }
+          }
+        }
+      }
+    }
+    if (q < S && valid) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        float v[4] = {accq[dt][0] * kScale, accq[dt][1] * kScale, accq[dt][2] * kScale, accq[dt][3] * kScale};
+        store4(dqkv + ((long long)b * S + q) * ld + h * 32 + 16 * dt + 4 * g, v);
+      }
+    }
+  }
+
+  // ---- the two waves of a head exchange partials: role 0 finishes dK (needs role 1's dK), role 1 finishes dV ----
+  __syncthreads();                                            // the images are dead: they carry the partials
+  f32x4* xbuf = (f32x4*)base;                                 // [2 partials][NKT][2][64 lanes] = 4 * IMG bytes
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      if (kt < nkt) xbuf[((role * NKT + kt) * 2 + dt) * 64 + lane] = role == 0 ? dv[kt][dt] : dk[kt][dt];
+    }
+  __syncthreads();
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    if (kt < nkt) {
+      const int key = kt * 16 + l15;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const f32x4 other = xbuf[(((1 - role) * NKT + kt) * 2 + dt) * 64 + lane];
+        // fixed order: role 0's partial + role 1's partial
+        const f32x4 tot = role == 0 ? dk[kt][dt] + other : other + dv[kt][dt];
+        if (key < S && valid) {
+          T* row = dqkv + ((long long)bk * S + key) * ld + h * 32 + 16 * dt + 4 * g;
+          if (role == 0) {
+            float a[4] = {tot[0] * kScale, tot[1] * kScale, tot[2] * kScale, tot[3] * kScale};
+            store4(row + D, a);
+          } else {
+            float c[4] = {tot[0], tot[1], tot[2], tot[3]};
+            store4(row + 2 * D, c);
+          }
+        }
       }
     }
   }
@@ -475,6 +688,21 @@ template <typename T, int SP>
 int launch_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int NB, int S, int H,
                int kv_shift, DropCfg dc, const eg_step_state* st, hipStream_t s) {
   const int nblk = (NB * H + 1) / 2;
+  static const int single = [] { const char* e = getenv("EYEGAZE_ATTN_BWD1"); return e ? atoi(e) : 0; }();
+  // Single sweep (each P / dS block evaluated once), opt-in: half the exp / hash work of the two-pass kernel but MEASURED SLOWER
+  // (cfg3 step 4.40 ms against 4.03 ms): 67 KB of LDS per workgroup and ~220 registers leave 2 waves per SIMD to cover a
+  // per-block MFMA -> exp / hash -> LDS write -> transposed read -> MFMA chain; kept for the record and for further work.
+  if (SP <= 128 && single) {
+    constexpr int lds1 = 2 * (4 * SP * 64 + 2 * SP * 4 + 2 * 2 * 32 * 64);
+    static bool attr1 = false;
+    if (!attr1) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<T, (SP <= 128 ? SP : 96)>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+      attr1 = true;
+    }
+    hipLaunchKernelGGL((attn_bwd1_kernel<T, (SP <= 128 ? SP : 96)>), dim3(nblk), dim3(256), lds1, s, (const T*)qkv, (const T*)ctx,
+                       (const T*)dctx, lse, (T*)dqkv, NB, S, H, kv_shift, dc, st);
+    return 0;
+  }
   constexpr int lds = 2 * (3 * SP * 64 + 2 * SP * 4);
   static bool attr = false;
   if (!attr) {
