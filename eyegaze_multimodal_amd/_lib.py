@@ -103,6 +103,7 @@ SIGNATURES = {
     "eg_gemm_tn": [C.POINTER(GemmTNDesc), _P],
     "eg_reduce_partials": [_P, _P, _L, _I, _L, _I, _P],
     "eg_gemm_tn_grouped": [_P, _I, _I, _I, _I, _I, _P],
+    "eg_gemm_tn_grouped256": [_P, _I, _I, _I, _I, _I, _P],
     "eg_reduce_table": [_P, _I, _I, _P],
     "eg_unpack_conv_wgrad": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eg_colsum": [_P, RowMap, _I, _I, _P, _I, _I, _P],

@@ -695,6 +695,171 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_grouped_kernel(const eg_tn_pro
   tn_body<T>(p, local / p.tiles_nk, local % p.tiles_nk, smem);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 weight-gradient tile (16-bit operands, N % 256 == 0, K % 256 == 0): 512 threads = 8 waves as 4 (k groups of 64) x 2
+// (n groups of 128), 4 x 8 accumulator tiles per wave.  A 128 x 128 tile streams 512 B per reduction row for 16 K outputs and
+// depends on its neighbours hitting the same rows in L2 at the same time (measured: 2.77 GB fetched for 1.63 GB of operands);
+// this tile streams 1024 B per row for 64 K outputs -- half the traffic per output before any sharing.  Same LDS image (rows of
+// 256 columns, 16-B chunks XOR-swizzled by tn_swz), same transposed fragment reads, same k-ordered accumulation per output
+// element as tn_body: the partial slabs are bit-identical to the 128 x 128 tile's for equal row splits.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void tn_body256(const GemmTN<T>& p, const int split, const int t, char* smem) {
+  constexpr int ROWB = 512, RS = 64, TILEB = RS * ROWB;       // 32 KiB per operand and stage
+  typedef typename H16<T>::frag frag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave >> 1, wn = wave & 1;
+  const int n0 = (t / p.tiles_k) * 256, k0 = (t % p.tiles_k) * 256;
+  const int mbeg = split * p.rows_per_split;
+  const int mend = min(p.M, mbeg + p.rows_per_split);
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // staging map: chunk id c = tid + 512*i -> row = c / 32, chunk-in-row = c % 32
+  u32x4 ry[4], rx[4];
+  auto load_tile = [&](int mt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 512 * i;
+      const int row = c >> 5, ch = c & 31;
+      const int m = mt + row;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      ry[i] = z;
+      rx[i] = z;
+      if (m < mend) {
+        ry[i] = *(const u32x4*)(p.dY + row_off(p.y, m) + n0 + ch * 8);
+        rx[i] = *(const u32x4*)(p.X + row_off(p.x, m) + k0 + ch * 8);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 512 * i;
+      const int row = c >> 5, ch = c & 31;
+      const int off = row * ROWB + ((ch ^ tn_swz(row)) << 4);
+      *(u32x4*)(smem + off) = ry[i];
+      *(u32x4*)(smem + TILEB + off) = rx[i];
+    }
+  };
+  const int nt = (mend - mbeg + RS - 1) / RS;
+  const bool do_bias = p.has_bias && (t % p.tiles_k) == 0;
+  float bsum = 0.f;
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  if (nt > 0) load_tile(mbeg);
+  for (int it = 0; it < nt; ++it) {
+    store_tile();
+    __syncthreads();
+    if (it + 1 < nt) load_tile(mbeg + (it + 1) * RS);
+#pragma unroll
+    for (int sub = 0; sub < RS / 32; ++sub) {
+      const char* bufY = smem + sub * 32 * ROWB;
+      const char* bufX = smem + TILEB + sub * 32 * ROWB;
+      frag yf[8], xf[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        s16x4 part[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = 8 * g + 4 * h + q;
+          const int cy = wn * 128 + i * 16 + 4 * pp;
+          part[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(bufY + r * ROWB + (((cy >> 3) ^ tn_swz(r)) << 4) + ((cy >> 2) & 1) * 8));
+        }
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 ty = {part[0][0], part[0][1], part[0][2], part[0][3], part[1][0], part[1][1], part[1][2], part[1][3]};
+        yf[i] = __builtin_bit_cast(frag, ty);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s16x4 part[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = 8 * g + 4 * h + q;
+          const int cx = wk * 64 + i * 16 + 4 * pp;
+          part[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(bufX + r * ROWB + (((cx >> 3) ^ tn_swz(r)) << 4) + ((cx >> 2) & 1) * 8));
+        }
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 tx = {part[0][0], part[0][1], part[0][2], part[0][3], part[1][0], part[1][1], part[1][2], part[1][3]};
+        xf[i] = __builtin_bit_cast(frag, tx);
+      }
+#pragma unroll
+      for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) acc[ki][ni] = H16<T>::mfma(xf[ki], yf[ni], acc[ki][ni]);
+      if (do_bias) {       // column sums of the dY tile: thread -> column tid & 255, rows 16 * (tid >> 8) .. +15 of the sub-stage
+        const int col = tid & 255, half = tid >> 8;
+        float s16 = 0.f;                                  // (summed per sub-stage first, as tn_tile_colsum does: same rounding)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int r = half * 16 + i;
+          s16 += H16<T>::ld(*(const T*)(bufY + r * ROWB + (((col >> 3) ^ tn_swz(r)) << 4) + (col & 7) * 2));
+        }
+        bsum += s16;
+      }
+    }
+    __syncthreads();
+  }
+  float* out = p.partial + (size_t)split * p.slab;
+  const int l15 = lane & 15;
+#pragma unroll
+  for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) {
+      const int n = n0 + wn * 128 + ni * 16 + l15;
+      const int k = k0 + wk * 64 + ki * 16 + 4 * g;
+      const int part = n / p.part_rows;
+      *(f32x4*)(out + (size_t)part * p.part_size + (size_t)(n - part * p.part_rows) * p.K + k) = acc[ki][ni];
+    }
+  if (do_bias) {
+    float* red = (float*)smem;
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < 256) {
+      const int n = n0 + tid;
+      const int part = n / p.part_rows;
+      out[(size_t)part * p.part_size + (size_t)p.part_rows * p.K + (n - part * p.part_rows)] = red[tid] + red[tid + 256];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_tn_grouped256_kernel(const eg_tn_problem* __restrict__ probs, int nprob,
+                                                                    int M, int splits, int rows_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int pi_s;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = nprob - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (probs[mid].blk0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    pi_s = lo;
+  }
+  __syncthreads();
+  const eg_tn_problem q = probs[pi_s];
+  GemmTN<T> p;
+  p.dY = (const T*)q.dY; p.X = (const T*)q.X; p.partial = (float*)q.partial;
+  p.y.row_stride = q.ldy; p.y.group_stride = 0; p.y.rows_per_group = 0;
+  p.x.row_stride = q.ldx; p.x.group_stride = 0; p.x.rows_per_group = 0;
+  p.M = M; p.N = q.N; p.K = q.K; p.splits = splits; p.rows_per_split = rows_per_split;
+  p.tiles_k = q.K / 256;
+  p.tiles_nk = p.tiles_k * (q.N / 256);
+  p.x_tile_stride = 256;
+  p.part_rows = q.part_rows > 0 ? q.part_rows : q.N;
+  p.has_bias = q.has_bias;
+  p.part_size = (long long)p.part_rows * q.K + (q.has_bias ? p.part_rows : 0);
+  p.slab = (long long)(q.N / p.part_rows) * p.part_size;
+  const int local = bid - q.blk0;
+  tn_body256<T>(p, local / p.tiles_nk, local % p.tiles_nk, smem);
+}
+
 // table-driven form of the reduce below: entry e sums `splits` slabs of n floats into out
 __global__ __launch_bounds__(256) void reduce_table_kernel(const eg_reduce_entry* __restrict__ tab, int nent) {
   __shared__ f32x4 red[32][8];
@@ -1050,6 +1215,29 @@ extern "C" int eg_gemm_tn_grouped(const eg_tn_problem* probs, int nprob, int tot
     hipLaunchKernelGGL(gemm_tn_grouped_kernel<float>, dim3(total_blocks), dim3(256), 2 * TNCfg<float>::STAGE_ROWS * TNCfg<float>::ROWB,
                        s, probs, nprob, M, splits, rps);
   EG_LAUNCH_CHECK("gemm_tn_grouped");
+  return 0;
+}
+
+// the same problem table served by 256 x 256 tiles: blk0 counts (N/256) * (K/256) * splits blocks per problem
+extern "C" int eg_gemm_tn_grouped256(const eg_tn_problem* probs, int nprob, int total_blocks, int M, int splits, int dtype,
+                                     void* stream) {
+  EG_CHECK(probs && nprob > 0 && total_blocks > 0 && M > 0 && splits > 0, "eg_gemm_tn_grouped256: bad arguments");
+  EG_CHECK(dtype == EG_BF16 || dtype == EG_F16, "eg_gemm_tn_grouped256: 16-bit dtypes only (got %d)", dtype);
+  int rps = (M + splits - 1) / splits;
+  rps = (rps + 63) / 64 * 64;
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int lds = 2 * 64 * 512;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_grouped256_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_grouped256_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(gemm_tn_grouped256_kernel<bf16_t>, dim3(total_blocks), dim3(512), lds, s, probs, nprob, M, splits, rps);
+  else
+    hipLaunchKernelGGL(gemm_tn_grouped256_kernel<f16_t>, dim3(total_blocks), dim3(512), lds, s, probs, nprob, M, splits, rps);
+  EG_LAUNCH_CHECK("gemm_tn_grouped256");
   return 0;
 }
 

@@ -508,7 +508,12 @@ class Engine:
         for l in range(cfg.num_layers):
             g[f"dYo{l}"], g[f"dYf{l}"] = self._t(M, d), self._t(M, d)
             g[f"dqkv{l}"], g[f"dh{l}"] = self._t(M, 3 * d), self._t(M, F)
-        splits = self.GROUP_SPLITS
+        # 16-bit dtypes: 256 x 256 tiles, one 512-thread workgroup per CU (72 tiles x 3 row splits = 216 blocks, one round);
+        # otherwise 128 x 128 tiles, three 256-thread workgroups per CU (288 tiles x 5 splits)
+        big = (self.dtype != EG_F32 and os.environ.get("EYEGAZE_TN256", "1") != "0"
+               and all(N % 256 == 0 and K % 256 == 0 for _, _, _, N, K, _ in probs))
+        splits = int(os.environ.get("EYEGAZE_GROUP_SPLITS256", "3")) if big else self.GROUP_SPLITS
+        tile = 256 if big else 128
         total = sum(N * K + N for _, _, _, N, K, _ in probs)
         g["wg_partial"] = self._t(splits * total, dtype=torch.float32)
         ln_names = [f"encoder.layers.{l}.{n}" for l in range(cfg.num_layers) for n in ("ln1", "ln2")]
@@ -540,7 +545,7 @@ class Engine:
                 base = ptr(g["wg_partial"]) + 4 * offs[pi]
                 e.dY, e.X, e.partial = ptr(g[dyn]), ptr(self.a[xn]), base
                 e.ldy, e.ldx, e.N, e.K, e.part_rows, e.has_bias, e.blk0 = ldy, K, N, K, N // len(names), 1, blk
-                blk += ((N + 127) // 128) * ((K + 127) // 128) * splits
+                blk += ((N + tile - 1) // tile) * ((K + tile - 1) // tile) * splits
                 r.partial, r.out, r.n, r.stride, r.splits, r.blk0 = base, fp.g_ptr(names[0] + ".weight"), slab, slab, splits, rblk
                 rblk += _reduce_blocks(slab, splits)
             for k, (i, n) in enumerate(lns):   # deferred LayerNorm gain / bias partials ride in the same reduce launch
@@ -565,7 +570,8 @@ class Engine:
         # are still in backward (one piece would hold every encoder bucket back until backward has finished)
         h = Lr // 2
         pieces = [tables(range(h, Lr)), tables(range(0, h))] if Lr >= 2 else [whole]
-        self._wg_plan = dict(whole, splits=splits, per_layer=per_layer, pieces=pieces, split_layer=h)
+        self._wg_plan = dict(whole, splits=splits, per_layer=per_layer, pieces=pieces, split_layer=h,
+                             entry="eg_gemm_tn_grouped256" if big else "eg_gemm_tn_grouped")
         return self._wg_plan
 
     def _wgrad_group_launch(self, piece=None):
@@ -574,7 +580,7 @@ class Engine:
         if self._wg_side is not None:          # the per-layer launches are already queued on the side stream: join it
             torch.cuda.current_stream(self.device).wait_stream(self._wg_side)
         else:
-            call("eg_gemm_tn_grouped", ptr(pl["tp"]), pl["n"], pl["blocks"], self.M, self._wg_plan["splits"], self.dtype, self.stream)
+            call(self._wg_plan["entry"], ptr(pl["tp"]), pl["n"], pl["blocks"], self.M, self._wg_plan["splits"], self.dtype, self.stream)
         call("eg_reduce_table", ptr(pl["rt"]), pl["nr"], pl["rblocks"], self.stream)
 
     def _wgrad_layer_async(self, l: int):
@@ -586,7 +592,7 @@ class Engine:
         ev = torch.cuda.Event()
         ev.record(cur)
         self._wg_side.wait_event(ev)
-        call("eg_gemm_tn_grouped", ptr(tab), 4, nblk, self.M, self._wg_plan["splits"], self.dtype, self._wg_side.cuda_stream)
+        call(self._wg_plan["entry"], ptr(tab), 4, nblk, self.M, self._wg_plan["splits"], self.dtype, self._wg_side.cuda_stream)
 
     def _ln_f(self, gname, y, stats):
         """forward LayerNorm spec for gemm(ln=...) — None when the fused epilogue is unavailable (d_model != 256)"""

@@ -240,6 +240,9 @@ typedef struct eg_reduce_entry {
   int32_t splits, blk0;
 } eg_reduce_entry;
 int eg_gemm_tn_grouped(const eg_tn_problem* probs, int nprob, int total_blocks, int M, int splits, int dtype, void* stream);
+/* The same table served by 256 x 256 tiles (16-bit dtypes; every N and K a multiple of 256; blk0 counts
+ * (N/256) * (K/256) * splits blocks per problem): half the operand traffic per output, bit-identical partial slabs. */
+int eg_gemm_tn_grouped256(const eg_tn_problem* probs, int nprob, int total_blocks, int M, int splits, int dtype, void* stream);
 int eg_reduce_table(const eg_reduce_entry* table, int nentries, int total_blocks, void* stream);
 /* out[i] = (accumulate ? out[i] : 0) + sum_s partial[s*split_stride + i]; used for dW, db, LayerNorm dgamma/dbeta */
 int eg_reduce_partials(const float* partial, float* out, int64_t n, int splits, int64_t split_stride, int accumulate,
