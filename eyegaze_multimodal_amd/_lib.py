@@ -83,7 +83,7 @@ class ReduceEntry(C.Structure):
 class GemmTNDesc(C.Structure):
     _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("partial", C.c_void_p), ("y", RowMap), ("x", RowMap),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("splits", C.c_int32), ("dtype", C.c_int32),
-                ("x_tile_stride", C.c_int64), ("part_rows", C.c_int32), ("has_bias", C.c_int32)]
+                ("x_tile_stride", C.c_int64), ("part_rows", C.c_int32), ("has_bias", C.c_int32), ("tile", C.c_int32)]
 
 
 _P, _I, _L, _F, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32

@@ -829,6 +829,13 @@ __device__ __forceinline__ void tn_body256(const GemmTN<T>& p, const int split, 
 }
 
 template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmTN<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  tn_body256<T>(p, bid / p.tiles_nk, bid % p.tiles_nk, smem);
+}
+
+template <typename T>
 __global__ __launch_bounds__(512, 2) void gemm_tn_grouped256_kernel(const eg_tn_problem* __restrict__ probs, int nprob,
                                                                     int M, int splits, int rows_per_split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1133,6 +1140,21 @@ static int launch_gemm_tn(const eg_gemm_tn_desc* d, hipStream_t s) {
   p.has_bias = d->has_bias ? 1 : 0;
   p.part_size = (long long)p.part_rows * d->K + (p.has_bias ? p.part_rows : 0);
   p.slab = (long long)(d->N / p.part_rows) * p.part_size;
+  if constexpr (sizeof(T) == 2) {
+    if (d->tile == 256) {
+      p.tiles_k = d->K / 256;
+      p.tiles_nk = p.tiles_k * (d->N / 256);
+      constexpr int lds256 = 2 * 64 * 512;
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        attr = true;
+      }
+      hipLaunchKernelGGL(gemm_tn256_kernel<T>, dim3(p.tiles_nk * d->splits), dim3(512), lds256, s, p);
+      EG_LAUNCH_CHECK("gemm_tn256");
+      return 0;
+    }
+  }
   const int lds = 2 * TNCfg<T>::STAGE_ROWS * TNCfg<T>::ROWB;
   hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(p.tiles_nk * d->splits), dim3(256), lds, s, p);
   EG_LAUNCH_CHECK("gemm_tn");
@@ -1151,6 +1173,9 @@ extern "C" int eg_gemm_tn(const eg_gemm_tn_desc* d, void* stream) {
   EG_CHECK(d->part_rows == 0 || (d->N % d->part_rows == 0 && d->part_rows % 4 == 0), "eg_gemm_tn: part_rows=%d must divide N", d->part_rows);
   EG_CHECK(!d->has_bias || d->K % 4 == 0, "eg_gemm_tn: fused bias sums need K %% 4 == 0");
   EG_CHECK(d->x_tile_stride == 0 || (d->x_tile_stride % al == 0 && d->K % 128 == 0), "eg_gemm_tn: x_tile_stride needs K %% 128 == 0");
+  EG_CHECK(d->tile == 0 || d->tile == 128 || (d->tile == 256 && d->dtype != EG_F32 && d->N % 256 == 0 && d->K % 256 == 0 &&
+                                              (d->x_tile_stride == 0 || d->x_tile_stride == 128)),
+           "eg_gemm_tn: tile=%d (256 needs a 16-bit dtype, N and K multiples of 256, contiguous X rows)", d->tile);
   hipStream_t s = (hipStream_t)stream;
   return d->dtype == EG_BF16 ? launch_gemm_tn<bf16_t>(d, s) : d->dtype == EG_F16 ? launch_gemm_tn<f16_t>(d, s) : launch_gemm_tn<float>(d, s);
 }

@@ -150,6 +150,7 @@ class Engine:
         self.probes = {}   # tag -> (start_event, end_event) recorded around that launch
         # LayerNorm forward / backward run in the epilogue of the adjacent N == d_model product (row-complete GEMM tile)
         self.fuse_ln = cfg.d_model == 256 and os.environ.get("EYEGAZE_FUSE_LN", "0") == "1"
+        self.cus = torch.cuda.get_device_properties(device).multi_processor_count if device.type == "cuda" else 256
         # feed-forward pair as one launch (csrc/ffn.hip): 16-bit compute dtypes, d_model == 256, d_ff a multiple of 128
         self.fuse_ffn = (dtype != EG_F32 and cfg.d_model == 256 and cfg.d_ff % 128 == 0 and not self.fuse_ln
                          and os.environ.get("EYEGAZE_FFN", "1") != "0")
@@ -441,7 +442,14 @@ class Engine:
         slab = N * K + (N if fused else 0)
         # one resident round: 256 CUs x 3 workgroups; rounding the split count UP would leave a nearly empty second round
         splits = max(1, min((M + 127) // 128, max(1, 768 // tiles), self.tn_cap // slab))
+        # big products on 16-bit operands: 256 x 256 tiles, one 512-thread workgroup per CU (conv-1: 25 tiles x 10 row splits)
+        big = (self.dtype != EG_F32 and N % 256 == 0 and K % 256 == 0 and not x_tile_stride and M * N * K >= (1 << 34)
+               and os.environ.get("EYEGAZE_TN256", "1") != "0")
+        if big:
+            t256 = (N // 256) * (K // 256)
+            splits = max(1, min((M + 63) // 64, max(1, self.cus // t256), self.tn_cap // slab))
         dsc = GemmTNDesc()
+        dsc.tile = 256 if big else 128
         dsc.dY, dsc.X, dsc.partial = dY, X, ptr(self.g["partial"])
         dsc.y = y or rowmap(N)
         dsc.x = x or rowmap(K)

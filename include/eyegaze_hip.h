@@ -220,6 +220,8 @@ typedef struct eg_gemm_tn_desc {
   int64_t x_tile_stride; /* 0/128 = contiguous X rows; else elements between consecutive 128-column tiles */
   int32_t part_rows;     /* 0 = N.  One split's slab is N/part_rows parts of [part_rows x K | part_rows bias sums]: */
   int32_t has_bias;      /* the layout of consecutive (weight, bias) parameters, so ONE eg_reduce_partials writes both */
+  int32_t tile;          /* 0 / 128: 128 x 128 tiles (256 threads); 256: 256 x 256 tiles (512 threads; 16-bit dtypes, N and K
+                            multiples of 256, contiguous X rows): half the operand traffic per output, same partial slabs */
 } eg_gemm_tn_desc;
 int eg_gemm_tn(const eg_gemm_tn_desc* d, void* stream);
 /* Grouped form: every weight-gradient product of the encoder in ONE launch (plain row-major operands, common

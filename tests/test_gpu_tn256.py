@@ -57,3 +57,31 @@ def test_tn256_partials_are_bit_identical_to_the_128_tile(M, splits, dtype):
             bb = tot[i * (P * K + P) + P * K: (i + 1) * (P * K + P)]
             assert float((w - dW[i * P:(i + 1) * P]).abs().max()) <= 1e-3 * max(1.0, float(dW.abs().max()))
             assert float((bb - db[i * P:(i + 1) * P]).abs().max()) <= 1e-3 * max(1.0, float(db.abs().max()))
+
+
+@pytest.mark.parametrize("M,splits", [(32768, 10), (1000, 4)])
+def test_single_problem_tn256_with_overlapping_conv_rows(M, splits):
+    """eg_gemm_tn(tile = 256) on the strided-conv operand layout (X rows overlap: row m starts 1024 elements after row m - 1 inside
+    a window, 6400 elements long) gives the same partial slabs as tile = 128."""
+    from eyegaze_multimodal_amd._lib import GemmTNDesc, rowmap
+    N, K, T2, stride, R0 = 256, 6400, 64, 1024, 64 * 1024 + 6400
+    groups = (M + T2 - 1) // T2
+    g = torch.Generator(device="cpu").manual_seed(7)
+    X = (torch.randn(groups * R0, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    dY = (torch.randn(M, N, generator=g) * 0.3).to(torch.bfloat16).to(DEV)
+    outs = []
+    for tile in (128, 256):
+        part = torch.full((splits * N * K,), 7.0, device=DEV)
+        d = GemmTNDesc()
+        d.dY, d.X, d.partial = ptr(dY), ptr(X), ptr(part)
+        d.y, d.x = rowmap(N), rowmap(stride, R0, T2)
+        d.M, d.N, d.K, d.splits, d.dtype, d.tile = M, N, K, splits, L.EG_BF16, tile
+        call("eg_gemm_tn", C.byref(d), 0)
+        torch.cuda.synchronize()
+        outs.append(part)
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    rows = torch.stack([X[(m // T2) * R0 + (m % T2) * stride:(m // T2) * R0 + (m % T2) * stride + K] for m in range(min(M, 1000))])
+    if M <= 1000:
+        ref = dY.double().cpu().T @ rows.double().cpu()
+        got = outs[1].view(splits, N, K).double().sum(0).cpu()
+        assert float((got - ref).abs().max()) <= 1e-3 * float(ref.abs().max())
