@@ -279,7 +279,8 @@ def main():
         # Per launch (averaged over that kernel's launches of a step): algorithmic FLOPs = 2*M*N*K, algorithmic bytes = each
         # distinct operand/output element once (Engine._gemm_bytes).  With d_model = 256 the products sit BELOW the ridge
         # (FLOP/B < peak_flops/peak_bw), so the binding roofline is HBM; the MFMA fraction is reported beside it.
-        ROUTES = {0: "gemm_nt_kernel", 1: "gemm_nt_wide_kernel", 2: "rs_gemm_kernel", 3: "gemm_nt_row_kernel", 4: "ffn_chain_kernel"}
+        ROUTES = {0: "gemm_nt_kernel", 1: "gemm_nt_wide_kernel", 2: "rs_gemm_kernel", 3: "gemm_nt_row_kernel", 4: "ffn_chain_kernel",
+                  5: "gemm_nt_tall_kernel"}
         peak = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS
         ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)
         nsteps_probed = (min(8, args.steps) if graphed is None else 4)

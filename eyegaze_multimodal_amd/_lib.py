@@ -49,7 +49,7 @@ class GemmDesc(C.Structure):
                 ("ln_mode", C.c_int32), ("row_tile", C.c_int32), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
                 ("ln_x", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_out", C.c_void_p), ("ln_out2", C.c_void_p),
                 ("ln_partial", C.c_void_p), ("ln_drop1_p", C.c_float), ("ln_drop2_p", C.c_float),
-                ("ln_drop1_site", C.c_uint32), ("ln_drop2_site", C.c_uint32)]
+                ("ln_drop1_site", C.c_uint32), ("ln_drop2_site", C.c_uint32), ("W_frag", C.c_void_p)]
 
 
 class FfnDesc(C.Structure):
@@ -99,6 +99,7 @@ SIGNATURES = {
     "eg_pack_convT_weight": [_P, _P, _I, _I, _I, _I, _I, _P],
     "eg_gemm_nt": [C.POINTER(GemmDesc), _P],
     "eg_gemm_nt_route": [C.POINTER(GemmDesc)],
+    "eg_frag_order_rows": [_P, _P, _I, _I, _I, _P],
     "eg_ffn_chain": [C.POINTER(FfnDesc), _P],
     "eg_gemm_tn": [C.POINTER(GemmTNDesc), _P],
     "eg_reduce_partials": [_P, _P, _L, _I, _L, _I, _P],

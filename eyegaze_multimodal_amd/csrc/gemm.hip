@@ -1066,12 +1066,15 @@ int eg_wide_gemm_try(const eg_gemm_desc* d, hipStream_t s); // widegemm.hip: 160
 
 bool eg_rs_gemm_ok(const eg_gemm_desc* d);
 bool eg_wide_gemm_ok(const eg_gemm_desc* d);
+bool eg_tall_gemm_ok(const eg_gemm_desc* d);                 // tallgemm.hip: one wave per SIMD, weights in fragment order
+int eg_tall_gemm_try(const eg_gemm_desc* d, hipStream_t s);
 static int gemm_knob(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 1; }
 
 // which kernel eg_gemm_nt launches for this descriptor (measurement aid: bench.py attributes its per-launch timings with it)
 extern "C" int eg_gemm_nt_route(const eg_gemm_desc* d) {
   if (!d) return -1;
-  static const int use_rs = gemm_knob("EYEGAZE_RS"), use_wide = gemm_knob("EYEGAZE_WIDE");
+  static const int use_rs = gemm_knob("EYEGAZE_RS"), use_wide = gemm_knob("EYEGAZE_WIDE"), use_tall = gemm_knob("EYEGAZE_TALL");
+  if (use_tall && eg_tall_gemm_ok(d)) return EG_ROUTE_TALL;
   if (use_wide && eg_wide_gemm_ok(d)) return EG_ROUTE_WIDE;
   if (use_rs && eg_rs_gemm_ok(d)) return EG_ROUTE_ROWSTREAM;
   if (d->ln_mode != 0 || d->row_tile) return EG_ROUTE_ROWTILE;
@@ -1098,7 +1101,12 @@ extern "C" int eg_gemm_nt(const eg_gemm_desc* d, void* stream) {
   EG_CHECK((long long)d->M * d->N < (1ll << 32), "eg_gemm_nt: M*N exceeds the 32-bit dropout index");
   EG_CHECK(((uintptr_t)d->A | (uintptr_t)d->W | (uintptr_t)d->C) % 16 == 0, "eg_gemm_nt: operands must be 16-B aligned");
   hipStream_t s = (hipStream_t)stream;
-  static const int use_rs = gemm_knob("EYEGAZE_RS"), use_wide = gemm_knob("EYEGAZE_WIDE");
+  static const int use_rs = gemm_knob("EYEGAZE_RS"), use_wide = gemm_knob("EYEGAZE_WIDE"), use_tall = gemm_knob("EYEGAZE_TALL");
+  if (use_tall) {                                  // N == 256, deep K, fragment-ordered weights at hand
+    const int rc = eg_tall_gemm_try(d, s);
+    if (rc == 0) return 0;
+    if (rc != -1) return eg_fail("tall gemm launch failed");
+  }
   if (use_wide) {                                  // N == 256 (any K): one workgroup per 160 whole rows
     const int rc = eg_wide_gemm_try(d, s);
     if (rc == 0) return 0;

@@ -181,6 +181,13 @@ class Engine:
         w["conv0"] = self._t(d, self.K0)
         w["conv1"] = self._t(d, self.k * d)
         w["conv1T"] = self._t(self.s, d, self.J * d)
+        # the same two in MFMA-fragment order for the tall (one wave per SIMD) tile: N == 256, K a multiple of 256, 16-bit
+        # (measured no faster than the wide tile -- csrc/tallgemm.hip -- so opt-in)
+        self.tall_conv = (self.dtype != EG_F32 and d == 256 and (self.k * d) % 256 == 0 and (self.J * d) % 256 == 0
+                          and os.environ.get("EYEGAZE_TALL_CONV", "0") == "1")
+        if self.tall_conv:
+            w["conv1f"] = self._t(d * self.k * d)
+            w["conv1Tf"] = self._t(self.s * d * self.J * d)
         w["pos"] = self._t(cfg.max_len, d)
         for l in list(range(L_)) + (["x"] if cfg.use_cross_attention else []):
             w[f"qkv{l}"] = self._t(3 * d, d)
@@ -324,12 +331,13 @@ class Engine:
     # thin wrappers
     # ------------------------------------------------------------------------------------------
     def gemm(self, A, W, Cout, M, N, K, *, a=None, c=None, r=None, p=None, ldw=None, bias=0, residual=0, gate=0,
-             out_pre=0, act=0, drop1=(0.0, 0), drop2=(0.0, 0), gate_scale=1.0, tag=None, seg=(0, 0), ln=None):
+             out_pre=0, act=0, drop1=(0.0, 0), drop2=(0.0, 0), gate_scale=1.0, tag=None, seg=(0, 0), ln=None, w_frag=0):
         """ln: LayerNorm fused into the epilogue of an N == 256 product (eg_gemm_desc.ln_*):
         dict(mode=1, gamma, beta, out, stats) or dict(mode=2, gamma, x, stats, out, out2, partial, d1, d2)."""
         probe = self.probes.get(tag) if tag else None
         dsc = self._gemm_desc(A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2,
                               gate_scale, seg, ln)
+        dsc.W_frag = w_frag or None
         if self.probe_all is not None:      # bench.py: HIP events around EVERY eg_gemm_nt launch of the timed region
             probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.probe_all.append((probe[0], probe[1], 2.0 * M * N * K,
@@ -698,6 +706,9 @@ class Engine:
         call("eg_pack_conv_weight", fp.p_ptr("temporal_conv.convs.1.weight"), ptr(w["conv1"]), d, d, self.k, d, self.k * d,
              dt, st)
         call("eg_pack_convT_weight", fp.p_ptr("temporal_conv.convs.1.weight"), ptr(w["conv1T"]), d, d, self.k, self.s, dt, st)
+        if self.tall_conv:
+            call("eg_frag_order_rows", ptr(w["conv1"]), ptr(w["conv1f"]), self.k * d, self.k * d, 1, st)
+            call("eg_frag_order_rows", ptr(w["conv1T"]), ptr(w["conv1Tf"]), self.J * d, self.J * d, self.s, st)
         self.p_cast(fp.p_ptr("pos_embed.pos_embed.weight"), ptr(w["pos"]), cfg.max_len * d)
 
         def attn_pack(pre, l):
@@ -756,7 +767,8 @@ class Engine:
         self.gemm(ptr(a["h0pad"]), ptr(w["conv1"]), ptr(a["x0"]) + self.off * d * es, NB * self.T2, d, self.k * d,
                   a=rowmap(self.s * d, self.R0 * d, self.T2), c=rowmap(d, S * d, self.T2),
                   r=rowmap(d, 0, self.T2), p=rowmap(d), bias=fp.p_ptr("temporal_conv.convs.1.bias"), act=L.ACT_RELU,
-                  drop1=(p01, SITE_CONV1), residual=ptr(w["pos"]) + self.off * d * es, out_pre=ptr(a["h1"]), tag="conv1_fwd")
+                  drop1=(p01, SITE_CONV1), residual=ptr(w["pos"]) + self.off * d * es, out_pre=ptr(a["h1"]), tag="conv1_fwd",
+                  w_frag=ptr(w["conv1f"]) if self.tall_conv else 0)
         # CLS rows (D:1157) + pos row 0
         call("eg_rows_bcast_f32", fp.p_ptr("cls_token"), fp.p_ptr("pos_embed.pos_embed.weight"), ptr(a["x0"]), NB, S, d, 1,
              0, 1, self.dtype, st)
@@ -1003,7 +1015,8 @@ class Engine:
         for ph in range(self.s):
             self.gemm(ptr(g["dy1pad"]), ptr(w["conv1T"]) + ph * d * self.J * d * es, ptr(g["dh0pad"]) + ph * d * es,
                       NB * self.U, d, self.J * d, a=rowmap(d, self.RY * d, self.U), c=rowmap(self.s * d, self.R0 * d, self.U),
-                      gate=ptr(a["h0pad"]) + ph * d * es, gate_scale=sc01)
+                      gate=ptr(a["h0pad"]) + ph * d * es, gate_scale=sc01,
+                      w_frag=(ptr(w["conv1Tf"]) + ph * d * self.J * d * es) if self.tall_conv else 0)
         h0map = rowmap(d, self.R0 * d, self.T1)
         self.wgrad(ptr(g["dh0pad"]) + self.pad * d * es, ptr(a["xt"]), fp.g_ptr("temporal_conv.convs.0.weight"),
                    NB * self.T1, d, self.K0, y=h0map, x=rowmap(self.s * self.Cp, self.Tp * self.Cp, self.T1),

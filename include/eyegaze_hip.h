@@ -159,13 +159,20 @@ typedef struct eg_gemm_desc {
   float* ln_partial;
   float ln_drop1_p, ln_drop2_p;
   uint32_t ln_drop1_site, ln_drop2_site;
+  /* Optional: the same W (N == 256 rows) in MFMA-fragment order as written by eg_frag_order_rows.  With it, deep products
+   * (K >= 1536, K % 256 == 0, 16-bit dtypes) run on the one-wave-per-SIMD tall tile whose weights go straight to registers. */
+  const void* W_frag;
 } eg_gemm_desc;
 int eg_gemm_nt(const eg_gemm_desc* d, void* stream);
 /* Which kernel eg_gemm_nt launches for `d` (no launch; a measurement aid so that per-launch timings can be attributed):
  * EG_ROUTE_TILED gemm_nt_kernel (128x128 tile), EG_ROUTE_WIDE gemm_nt_wide_kernel (160x256, N == 256),
- * EG_ROUTE_ROWSTREAM rs_gemm_kernel (K == 256, register-stationary weights), EG_ROUTE_ROWTILE gemm_nt_row_kernel. */
-enum { EG_ROUTE_TILED = 0, EG_ROUTE_WIDE = 1, EG_ROUTE_ROWSTREAM = 2, EG_ROUTE_ROWTILE = 3 };
+ * EG_ROUTE_ROWSTREAM rs_gemm_kernel (K == 256, register-stationary weights), EG_ROUTE_ROWTILE gemm_nt_row_kernel,
+ * EG_ROUTE_TALL gemm_nt_tall_kernel (N == 256, K >= 1536, W_frag given: one wave per SIMD, weights straight to registers). */
+enum { EG_ROUTE_TILED = 0, EG_ROUTE_WIDE = 1, EG_ROUTE_ROWSTREAM = 2, EG_ROUTE_ROWTILE = 3, EG_ROUTE_TALL = 5 };
 int eg_gemm_nt_route(const eg_gemm_desc* d);
+/* `count` stacked [256, ldw] row-major 16-bit weights (K columns used) -> count x [K/32][4][4][64][8]: the fragment order
+ * eg_gemm_desc.W_frag expects */
+int eg_frag_order_rows(const void* src, void* dst, int K, int ldw, int count, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * eg_ffn_chain — the two products of the position-wise feed-forward block (A:264-272) in one launch, d_model == 256:
