@@ -360,25 +360,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
 
 // ------------------------------------------------------------------------------------------------
 // Single-sweep backward (S <= 128): every 16 x 16 block of P / dS is computed ONCE.
-// The two-pass kernel above evaluates exp and the dropout hash of each block twice (pass B in the transposed layout, with one
-// hash per element instead of one per pair) and is VALU-bound on exactly that.  Here a wave takes alternate query tiles; per
-// block it forms, in the key-rows / query-lanes layout, P*mask and dS, feeds dS straight into the dQ MFMA (as pass A does),
-// and TRANSPOSES both through a 4-KB wave-private LDS image -- written as 8-B row pieces, read back with ds_read_b64_tr_b16
-// as the B operands (key lanes, query k-slots) of the dV / dK MFMAs.  A wave's image holds one query tile in its half of the
-// 32 k-slots; the other half stays zero (a wave's tiles all have the same parity), so the A operands -- the transposed dO / Q
-// fragments of the tile PAIR -- need no masking.  dK / dV accumulate in registers over the wave's query tiles (16 registers
-// per key tile); the two waves of a head exchange one partial each through LDS (role 0 finishes dK, role 1 dV): a fixed order,
-// so results stay bit-reproducible.
+// The two-pass kernel above evaluates exp and the dropout hash of each block twice (pass B in the transposed layout) and is
+// VALU-issue-bound on exactly that.  Here a wave owns alternate KEY tiles and walks all query tiles in pairs.  Per block it
+// forms, in the key-rows / query-lanes layout, P*mask and dS; dS goes straight into the dQ MFMA of its query tile (B operand:
+// query lanes, key k-slots -- the other key tile of the pair is a zero half), and both are TRANSPOSED through a 2-KB
+// wave-private LDS image (written as 8-B row pieces, read back with ds_read_b64_tr_b16 as B operands with key lanes and the
+// query pair in the k-slots) for the dV / dK MFMAs of the wave's key tile.  dK / dV of a key tile are complete in the wave
+// (16 registers, stored once per key tile); dQ accumulates per query tile across the wave's key tiles (8 registers per tile) and
+// the two waves of a head exchange halves through LDS in a fixed order (bit-reproducible).  Registers: 8 NKT + 16 accumulators
+// instead of the 16 NKT of a query-major sweep, LDS 23 KB per head: three workgroups per CU, as the two-pass kernel.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int SP>
-__global__ __launch_bounds__(256) void attn_bwd1_kernel(const T* __restrict__ qkv, const T* __restrict__ ctx,
+__global__ __launch_bounds__(256, SP <= 96 ? 3 : 2) void attn_bwd1_kernel(const T* __restrict__ qkv, const T* __restrict__ ctx,
                                                         const T* __restrict__ dctx, const float* __restrict__ lse,
                                                         T* __restrict__ dqkv, int NB, int S, int H, int kv_shift,
                                                         DropCfg dc, const eg_step_state* st) {
   constexpr int NKT = SP / 16;
   constexpr int IMG = SP * 64;
-  constexpr int SCR = 2 * 32 * 64;                            // one wave's P and dS images: [32 query slots][32 keys]
-  constexpr int WB = 4 * IMG + 2 * SP * 4 + 2 * SCR;
+  constexpr int SCR = 2 * 32 * 32;                            // one wave's P and dS images: [32 query slots][16 keys] each
+  constexpr int WB = 3 * IMG + 2 * SP * 4 + 2 * SCR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, role = wave & 1;
   const int l15 = lane & 15, g = lane >> 4;
@@ -397,17 +397,14 @@ __global__ __launch_bounds__(256) void attn_bwd1_kernel(const T* __restrict__ qk
   char* base = smem + (wave >> 1) * WB;
   char* qimg = base;
   char* kimg = base + IMG;
-  char* vimg = base + 2 * IMG;
-  char* doimg = base + 3 * IMG;
-  float* lsel = (float*)(base + 4 * IMG);
+  char* doimg = base + 2 * IMG;
+  float* lsel = (float*)(base + 3 * IMG);
   float* dl = lsel + SP;
-  char* pimg = base + 4 * IMG + 2 * SP * 4 + role * SCR;
-  char* simg = pimg + 32 * 64;
+  char* pimg = base + 3 * IMG + 2 * SP * 4 + role * SCR;
+  char* simg = pimg + 32 * 32;
   stage_rows<T>(qimg, qbase, ld, S, SP, lane + 64 * role, 128);
   stage_rows<T>(kimg, kbase, ld, S, SP, lane + 64 * role, 128);
-  stage_rows<T>(vimg, vbase, ld, S, SP, lane + 64 * role, 128);
   stage_rows<T>(doimg, dobase, D, S, SP, lane + 64 * role, 128);
-  for (int i = lane; i < SCR / 16; i += 64) *(u32x4*)(pimg + i * 16) = (u32x4){0u, 0u, 0u, 0u};
   for (int q = lane + 64 * role; q < SP; q += 128) {
     float l = 0.f, dsum = 0.f;
     if (q < S) {
@@ -431,124 +428,112 @@ __global__ __launch_bounds__(256) void attn_bwd1_kernel(const T* __restrict__ qk
   const uint32_t Sp2 = (uint32_t)((S + 1) & ~1);
   __syncthreads();
 
-  f32x4 dk[NKT][2], dv[NKT][2];
+  f32x4 accq[NKT][2];
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
+  for (int qt = 0; qt < NKT; ++qt)
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      dk[kt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      dv[kt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-  // this wave's 8-B piece of an image row: query slot 16*role + l15, key columns 16*t + 4g .. +3 of the pair
-  const int srow = 16 * role + l15;
+    for (int dt = 0; dt < 2; ++dt) accq[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int qq = l15 >> 2, pp = l15 & 3;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  for (int qt = role; qt < nkt; qt += 2) {
-    const int q = qt * 16 + l15;
-    const FR<T> qf = ld_frag_lds_row<T>(qimg, q, g);
-    const FR<T> dof = ld_frag_lds_row<T>(doimg, q, g);
-    const float lq = lsel[q], dq = dl[q];
-    const uint32_t rowidx = (headidx + (uint32_t)q) * Sp2;
-    FR<T> dotr[2], qtr[2];
+  for (int kt = role; kt < nkt; kt += 2) {
+    const int key = kt * 16 + l15;
+    const FR<T> kfr = ld_frag_global<T>(kbase + (long long)key * ld + g * 8, key < S);
+    const FR<T> vfr = ld_frag_global<T>(vbase + (long long)key * ld + g * 8, key < S);
+    FR<T> ktr[2];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      dotr[dt] = ld_frag_lds_tr<T>(doimg, 32 * (qt >> 1), dt, lane);
-      qtr[dt] = ld_frag_lds_tr<T>(qimg, 32 * (qt >> 1), dt, lane);
-    }
-    f32x4 accq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    for (int dt = 0; dt < 2; ++dt) ktr[dt] = ld_frag_lds_tr<T>(kimg, 32 * (kt >> 1), dt, lane);
+    f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
 #pragma unroll
-    for (int kp = 0; kp < NKT / 2; ++kp) {
-      if (2 * kp < nkt) {
-        f32x4 ds2[2];
+    for (int qp = 0; qp < NKT / 2; ++qp) {
+      if (2 * qp < nkt) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int kt = 2 * kp + t;
-          ds2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (kt < nkt) {
-            const FR<T> kfr = ld_frag_lds_row<T>(kimg, kt * 16 + l15, g);
-            const FR<T> vfr = ld_frag_lds_row<T>(vimg, kt * 16 + l15, g);
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 sT = H16<T>::mfma(kfr, qf, z);
-            const f32x4 dpT = H16<T>::mfma(vfr, dof, z);
-            float m[4] = {1.f, 1.f, 1.f, 1.f};
-            eg_dropout_run<4>(m, dc, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g));
-            float pd[4], dsv[4];
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int qt = 2 * qp + h2;
+          const int q = qt * 16 + l15;
+          const FR<T> qf = ld_frag_lds_row<T>(qimg, q, g);
+          const FR<T> dof = ld_frag_lds_row<T>(doimg, q, g);
+          const float lq = lsel[q], dq = dl[q];
+          const f32x4 sT = H16<T>::mfma(kfr, qf, zero4);
+          const f32x4 dpT = H16<T>::mfma(vfr, dof, zero4);
+          float m[4] = {1.f, 1.f, 1.f, 1.f};
+          eg_dropout_run<4>(m, dc, seed_lo, seed_hi, (headidx + (uint32_t)q) * Sp2 + (uint32_t)(kt * 16 + 4 * g));
+          float pd[4];
+          f32x4 dsv;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int key = kt * 16 + 4 * g + r;
-              const float p = (key < S && q < S) ? __expf(sT[r] * kScale - lq) : 0.f;
-              pd[r] = p * m[r];
-              dsv[r] = p * (dpT[r] * m[r] - dq);
-              ds2[t][r] = dsv[r];
-            }
-            const int off = img_chunk_off(srow, 2 * t + (g >> 1)) + ((g & 1) << 3);
-            u32x2 pw, sw;
-            pw[0] = H16<T>::pack2(pd[0], pd[1]);  pw[1] = H16<T>::pack2(pd[2], pd[3]);
-            sw[0] = H16<T>::pack2(dsv[0], dsv[1]); sw[1] = H16<T>::pack2(dsv[2], dsv[3]);
-            *(u32x2*)(pimg + off) = pw;
-            *(u32x2*)(simg + off) = sw;
+          for (int r = 0; r < 4; ++r) {
+            const int kk = kt * 16 + 4 * g + r;
+            const float p = (kk < S && q < S) ? __expf(sT[r] * kScale - lq) : 0.f;
+            pd[r] = p * m[r];
+            dsv[r] = p * (dpT[r] * m[r] - dq);
           }
+          // dQ of this query tile: dS is the B operand as it stands (query lanes, key k-slots); the other key tile of the pair is zero
+          const FR<T> dsf = (kt & 1) ? pack_frag<T>(zero4, dsv) : pack_frag<T>(dsv, zero4);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) accq[qt][dt] = H16<T>::mfma(ktr[dt], dsf, accq[qt][dt]);
+          // the block into the wave's images: query slot 16 h2 + l15, keys 4g .. 4g+3 (8 B of a 32-B row)
+          const int off = (16 * h2 + l15) * 32 + g * 8;
+          u32x2 pw, sw;
+          pw[0] = H16<T>::pack2(pd[0], pd[1]);   pw[1] = H16<T>::pack2(pd[2], pd[3]);
+          sw[0] = H16<T>::pack2(dsv[0], dsv[1]); sw[1] = H16<T>::pack2(dsv[2], dsv[3]);
+          *(u32x2*)(pimg + off) = pw;
+          *(u32x2*)(simg + off) = sw;
         }
-        // dQ: dS is already the B operand (query lanes, key k-slots)
-        const FR<T> dsf = pack_frag<T>(ds2[0], ds2[1]);
+        // dV, dK of this key tile: the transposed blocks (key lanes, the query pair in the k-slots) against dO^T / Q^T
+        s16x4 pa[2], sa[2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int off = (16 * h2 + 4 * g + qq) * 32 + pp * 8;
+          pa[h2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pimg + off));
+          sa[h2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(simg + off));
+        }
+        const s16x8 pt = {pa[0][0], pa[0][1], pa[0][2], pa[0][3], pa[1][0], pa[1][1], pa[1][2], pa[1][3]};
+        const s16x8 stt = {sa[0][0], sa[0][1], sa[0][2], sa[0][3], sa[1][0], sa[1][1], sa[1][2], sa[1][3]};
+        const FR<T> pdf = __builtin_bit_cast(FR<T>, pt), dsT = __builtin_bit_cast(FR<T>, stt);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const FR<T> ktr = ld_frag_lds_tr<T>(kimg, 32 * kp, dt, lane);
-          accq[dt] = H16<T>::mfma(ktr, dsf, accq[dt]);
-        }
-        // dV, dK: the transposed blocks (key lanes, query k-slots) come back from the wave's images
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int kt = 2 * kp + t;
-          if (kt < nkt) {
-            const FR<T> pdf = ld_frag_lds_tr<T>(pimg, 0, t, lane);
-            const FR<T> dsT = ld_frag_lds_tr<T>(simg, 0, t, lane);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-              dv[kt][dt] = H16<T>::mfma(dotr[dt], pdf, dv[kt][dt]);
-              dk[kt][dt] = H16<T>::mfma(qtr[dt], dsT, dk[kt][dt]);
-            }
-          }
+          const FR<T> dotr = ld_frag_lds_tr<T>(doimg, 32 * qp, dt, lane);
+          dv[dt] = H16<T>::mfma(dotr, pdf, dv[dt]);
+          const FR<T> qtr = ld_frag_lds_tr<T>(qimg, 32 * qp, dt, lane);
+          dk[dt] = H16<T>::mfma(qtr, dsT, dk[dt]);
         }
       }
     }
-    if (q < S && valid) {
+    if (key < S && valid) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        float v[4] = {accq[dt][0] * kScale, accq[dt][1] * kScale, accq[dt][2] * kScale, accq[dt][3] * kScale};
-        store4(dqkv + ((long long)b * S + q) * ld + h * 32 + 16 * dt + 4 * g, v);
+        float a[4] = {dk[dt][0] * kScale, dk[dt][1] * kScale, dk[dt][2] * kScale, dk[dt][3] * kScale};
+        float c[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
+        T* row = dqkv + ((long long)bk * S + key) * ld + h * 32 + 16 * dt + 4 * g;
+        store4(row + D, a);
+        store4(row + 2 * D, c);
       }
     }
   }
 
-  // ---- the two waves of a head exchange partials: role 0 finishes dK (needs role 1's dK), role 1 finishes dV ----
+  // ---- dQ: role 0 finishes query tiles [0, NKT/2), role 1 the rest; each hands the other its partial of the other's tiles ----
   __syncthreads();                                            // the images are dead: they carry the partials
-  f32x4* xbuf = (f32x4*)base;                                 // [2 partials][NKT][2][64 lanes] = 4 * IMG bytes
+  f32x4* xbuf = (f32x4*)base;                                 // [2 roles][NKT/2][2][64 lanes]
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
+  for (int i = 0; i < NKT / 2; ++i) {
+    const int qt = (1 - role) * (NKT / 2) + i;                // a tile the OTHER wave finishes
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      if (kt < nkt) xbuf[((role * NKT + kt) * 2 + dt) * 64 + lane] = role == 0 ? dv[kt][dt] : dk[kt][dt];
-    }
+    for (int dt = 0; dt < 2; ++dt) xbuf[((role * (NKT / 2) + i) * 2 + dt) * 64 + lane] = role ? accq[i][dt] : accq[NKT / 2 + i][dt];
+    (void)qt;
+  }
   __syncthreads();
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    if (kt < nkt) {
-      const int key = kt * 16 + l15;
+  for (int i = 0; i < NKT / 2; ++i) {
+    const int qt = role * (NKT / 2) + i;
+    const int q = qt * 16 + l15;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const f32x4 other = xbuf[(((1 - role) * NKT + kt) * 2 + dt) * 64 + lane];
-        // fixed order: role 0's partial + role 1's partial
-        const f32x4 tot = role == 0 ? dk[kt][dt] + other : other + dv[kt][dt];
-        if (key < S && valid) {
-          T* row = dqkv + ((long long)bk * S + key) * ld + h * 32 + 16 * dt + 4 * g;
-          if (role == 0) {
-            float a[4] = {tot[0] * kScale, tot[1] * kScale, tot[2] * kScale, tot[3] * kScale};
-            store4(row + D, a);
-          } else {
-            float c[4] = {tot[0], tot[1], tot[2], tot[3]};
-            store4(row + 2 * D, c);
-          }
-        }
+    for (int dt = 0; dt < 2; ++dt) {
+      const f32x4 other = xbuf[(((1 - role) * (NKT / 2) + i) * 2 + dt) * 64 + lane];
+      const f32x4 mine = role ? accq[NKT / 2 + i][dt] : accq[i][dt];
+      const f32x4 tot = role ? other + mine : mine + other;    // fixed order: role 0's partial + role 1's partial
+      if (q < S && valid) {
+        float v[4] = {tot[0] * kScale, tot[1] * kScale, tot[2] * kScale, tot[3] * kScale};
+        store4(dqkv + ((long long)b * S + q) * ld + h * 32 + 16 * dt + 4 * g, v);
       }
     }
   }
@@ -688,12 +673,13 @@ template <typename T, int SP>
 int launch_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, void* dqkv, int NB, int S, int H,
                int kv_shift, DropCfg dc, const eg_step_state* st, hipStream_t s) {
   const int nblk = (NB * H + 1) / 2;
-  static const int single = [] { const char* e = getenv("EYEGAZE_ATTN_BWD1"); return e ? atoi(e) : 0; }();
-  // Single sweep (each P / dS block evaluated once), opt-in: half the exp / hash work of the two-pass kernel but MEASURED SLOWER
-  // (cfg3 step 4.40 ms against 4.03 ms): 67 KB of LDS per workgroup and ~220 registers leave 2 waves per SIMD to cover a
-  // per-block MFMA -> exp / hash -> LDS write -> transposed read -> MFMA chain; kept for the record and for further work.
-  if (SP <= 128 && single) {
-    constexpr int lds1 = 2 * (4 * SP * 64 + 2 * SP * 4 + 2 * 2 * 32 * 64);
+  static const int single = [] { const char* e = getenv("EYEGAZE_ATTN_BWD1"); return e ? atoi(e) : 1; }();
+  // Single sweep (each P / dS block evaluated once; key-major, see attn_bwd1_kernel) for S <= 96: cfg3 step 3.87 -> 3.78 ms, cfg5
+  // 5.63 -> 5.54 ms.  Longer sequences keep the two-pass kernel: at SP = 128 the 8 NKT + 16 accumulator registers leave two waves
+  // per SIMD and the a5 step measured 9.04 against 8.96 ms.  EYEGAZE_ATTN_BWD1=0 forces the two-pass kernel, =2 the single sweep
+  // wherever it is instantiated (S <= 128).
+  if ((SP <= 96 && single) || (SP <= 128 && single == 2)) {
+    constexpr int lds1 = 2 * (3 * SP * 64 + 2 * SP * 4 + 2 * 2 * 32 * 32);
     static bool attr1 = false;
     if (!attr1) {
       (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<T, (SP <= 128 ? SP : 96)>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
