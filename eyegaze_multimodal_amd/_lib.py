@@ -61,7 +61,8 @@ class FfnDesc(C.Structure):
                 ("M", C.c_int32), ("F", C.c_int32), ("act1", C.c_int32), ("dtype", C.c_int32),
                 ("drop_h_p", C.c_float), ("drop_c1_p", C.c_float), ("drop_c2_p", C.c_float),
                 ("drop_h_site", C.c_uint32), ("drop_c1_site", C.c_uint32), ("drop_c2_site", C.c_uint32),
-                ("gate_scale", C.c_float)]
+                ("gate_scale", C.c_float),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_out", C.c_void_p), ("ln_stats", C.c_void_p)]
 
 
 class PackEntry(C.Structure):

@@ -150,6 +150,10 @@ class Engine:
         self.probes = {}   # tag -> (start_event, end_event) recorded around that launch
         # LayerNorm forward / backward run in the epilogue of the adjacent N == d_model product (row-complete GEMM tile)
         self.fuse_ln = cfg.d_model == 256 and os.environ.get("EYEGAZE_FUSE_LN", "0") == "1"
+        # norm2 in the FFN chain's epilogue (the workgroup owns whole rows): parity-tested, measured EQUAL to the stand-alone
+        # LayerNorm launch (3.795 vs 3.790 ms / step: the epilogue's extra 17 MB store and three barriers cost what the 8.5 us
+        # launch cost), so opt-in
+        self.ffn_ln = os.environ.get("EYEGAZE_FFN_LN", "0") == "1"
         self.cus = torch.cuda.get_device_properties(device).multi_processor_count if device.type == "cuda" else 256
         # feed-forward pair as one launch (csrc/ffn.hip): 16-bit compute dtypes, d_model == 256, d_ff a multiple of 128
         self.fuse_ffn = (dtype != EG_F32 and cfg.d_model == 256 and cfg.d_ff % 128 == 0 and not self.fuse_ln
@@ -350,7 +354,7 @@ class Engine:
             probe[1].record(torch.cuda.current_stream(self.device))
 
     def ffn(self, A, W1f, W2f, H, Cout, M, F, *, bias1=0, bias2=0, act1=0, residual=0, gate=0, bits_out=0, bits_in=0,
-            drop_h=(0.0, 0), drop_c1=(0.0, 0), drop_c2=(0.0, 0), gate_scale=1.0):
+            drop_h=(0.0, 0), drop_c1=(0.0, 0), drop_c2=(0.0, 0), gate_scale=1.0, ln=None):
         """eg_ffn_chain: H = epi1(A W1^T), C = epi2(H W2^T) in one launch (weights in fragment order)."""
         d = self.cfg.d_model
         dsc = L.FfnDesc()
@@ -364,11 +368,13 @@ class Engine:
         dsc.drop_c1_p, dsc.drop_c1_site = drop_c1
         dsc.drop_c2_p, dsc.drop_c2_site = drop_c2
         dsc.gate_scale = gate_scale
+        if ln:                              # (gamma, beta, out, stats): the LayerNorm that follows the block, in the same launch
+            dsc.ln_gamma, dsc.ln_beta, dsc.ln_out, dsc.ln_stats = ln
         probe = None
         if self.probe_all is not None:      # bench.py: timed like the eg_gemm_nt launches, as its own kernel (route 4)
             probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             es = self.es
-            nbytes = es * (M * d * (2 + (1 if residual and residual != A else 0)) + M * F * (1 + (1 if gate else 0)) + 2 * F * d) \
+            nbytes = es * (M * d * (2 + (1 if residual and residual != A else 0) + (1 if ln else 0)) + M * F * (1 + (1 if gate else 0)) + 2 * F * d) \
                 + (M * F // 8 if (bits_out or bits_in) else 0) + 4 * (F + d)
             self.probe_all.append((probe[0], probe[1], 4.0 * M * F * d, float(nbytes), (M, F, d), 4))
             probe[0].record(torch.cuda.current_stream(self.device))
@@ -789,14 +795,16 @@ class Engine:
                 self.ffn(ptr(a[f"y1_{l}"]), ptr(w[f"w1f{l}"]), ptr(w[f"w2f{l}"]), ptr(a[f"hff{l}"]), ptr(a[f"r2_{l}"]), M, F,
                          bias1=fp.p_ptr(pre + "ffn.linear1.bias"), bias2=fp.p_ptr(pre + "ffn.linear2.bias"), act1=L.ACT_RELU,
                          residual=ptr(a[f"y1_{l}"]), drop_h=(p, sites["ffn_a"]), drop_c1=(p, sites["ffn_b"]),
-                         drop_c2=(p, sites["drop2"]), bits_out=ptr(a[f"gbits{l}"]))
+                         drop_c2=(p, sites["drop2"]), bits_out=ptr(a[f"gbits{l}"]),
+                         ln=((fp.p_ptr(pre + "ln2.weight"), fp.p_ptr(pre + "ln2.bias"), ptr(a[f"x{l + 1}"]), ptr(a[f"st2_{l}"]))
+                             if self.ffn_ln else None))
             else:
                 self.gemm(ptr(a[f"y1_{l}"]), ptr(w[f"w1{l}"]), ptr(a[f"hff{l}"]), M, F, d, bias=fp.p_ptr(pre + "ffn.linear1.bias"),
                           act=L.ACT_RELU, drop1=(p, sites["ffn_a"]))
                 self.gemm(ptr(a[f"hff{l}"]), ptr(w[f"w2{l}"]), ptr(a[f"r2_{l}"]), M, d, F, bias=fp.p_ptr(pre + "ffn.linear2.bias"),
                           drop1=(p, sites["ffn_b"]), drop2=(p, sites["drop2"]), residual=ptr(a[f"y1_{l}"]),
                           ln=self._ln_f(pre + "ln2", a[f"x{l + 1}"], a[f"st2_{l}"]))
-            if not self.fuse_ln:
+            if not self.fuse_ln and not (self.fuse_ffn and self.ffn_ln):
                 self.ln_fwd(a[f"r2_{l}"], pre + "ln2", a[f"x{l + 1}"], a[f"st2_{l}"])
         Lr = cfg.num_layers
         self.ln_fwd(a[f"x{Lr}"], "encoder.norm", a["zn"], a["stf"])

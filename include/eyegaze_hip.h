@@ -205,6 +205,12 @@ typedef struct eg_ffn_desc {
   float drop_h_p, drop_c1_p, drop_c2_p;
   uint32_t drop_h_site, drop_c1_site, drop_c2_site;
   float gate_scale;
+  /* Optional (forward form): LayerNorm(eps 1e-5) of the C rows as stored, in the same launch (A:295: the encoder layer's norm2
+   * follows this block): ln_out[M,256] (row stride ldc) = LN(C) * ln_gamma + ln_beta, ln_stats[M,2] = (mean, rstd). */
+  const float* ln_gamma;
+  const float* ln_beta;
+  void* ln_out;
+  float* ln_stats;
 } eg_ffn_desc;
 int eg_ffn_chain(const eg_ffn_desc* d, void* stream);
 int64_t eg_ffn_gate_bits_bytes(int M, int F);
