@@ -343,7 +343,7 @@ class Engine:
                               gate_scale, seg, ln)
         dsc.W_frag = w_frag or None
         if self.probe_all is not None:      # bench.py: HIP events around EVERY eg_gemm_nt launch of the timed region
-            probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            probe = self._probe_pair()
             self.probe_all.append((probe[0], probe[1], 2.0 * M * N * K,
                                    self._gemm_bytes(M, N, K, a, seg, residual, gate, out_pre, ln, Cout), (M, N, K),
                                    L.lib().eg_gemm_nt_route(C.byref(dsc))))
@@ -352,6 +352,14 @@ class Engine:
         call("eg_gemm_nt", C.byref(dsc), self.stream)
         if probe:
             probe[1].record(torch.cuda.current_stream(self.device))
+
+    def _probe_pair(self):
+        """A (start, end) event pair for a timed launch: from bench.py's pre-created pool when there is one -- creating a
+        hipEvent costs the host far more than recording one, and fresh events inside the timed region made short runs host-bound."""
+        pool = getattr(self, "probe_pool", None)
+        if pool:
+            return pool.pop()
+        return (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
     def ffn(self, A, W1f, W2f, H, Cout, M, F, *, bias1=0, bias2=0, act1=0, residual=0, gate=0, bits_out=0, bits_in=0,
             drop_h=(0.0, 0), drop_c1=(0.0, 0), drop_c2=(0.0, 0), gate_scale=1.0, ln=None):
@@ -372,7 +380,7 @@ class Engine:
             dsc.ln_gamma, dsc.ln_beta, dsc.ln_out, dsc.ln_stats = ln
         probe = None
         if self.probe_all is not None:      # bench.py: timed like the eg_gemm_nt launches, as its own kernel (route 4)
-            probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            probe = self._probe_pair()
             es = self.es
             nbytes = es * (M * d * (2 + (1 if residual and residual != A else 0) + (1 if ln else 0)) + M * F * (1 + (1 if gate else 0)) + 2 * F * d) \
                 + (M * F // 8 if (bits_out or bits_in) else 0) + 4 * (F + d)
