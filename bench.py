@@ -250,7 +250,7 @@ def main():
     probes.clear()
     # the timed region's probe events are created (and recorded once, which is what materialises a hipEvent) HERE, outside it:
     # inside, a probed launch costs two hipEventRecord calls and the host stays ahead of the GPU
-    n_probe_steps = 0 if graphed is not None else min(8, args.steps)
+    n_probe_steps = 0 if graphed is not None else min(8, max(2, args.steps // 5), args.steps)   # 8 of 100 steps, 4 of the driver's 20
     stream0 = torch.cuda.current_stream(dev)
     pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             for _ in range(n_probe_steps * launches_per_step)]
@@ -264,6 +264,12 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    # no cyclic-GC pause inside the timed region: a step allocates a few hundred short-lived ctypes descriptors and event
+    # tuples, and a generation-2 collection over the process' tensors costs tens of milliseconds -- invisible in 100 steps,
+    # a doubling of ms/step in a 20-step run
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, probe=(i < n_probe_steps))  # events on the launch stream, read after the region
@@ -271,6 +277,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if graphed is not None:
         for i in range(4):
             step(args.warmup + args.steps + i, probe=True, eager=True)
