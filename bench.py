@@ -35,6 +35,11 @@ WORKLOADS = {
              "BASELINE configs[4]: + STFT image -> 2-D CNN tokens per channel (third modality), cross-attention fusion"),
     "a5": (dict(use_spectrogram=True, use_ibs=True, use_robust_ibs=True, use_cross_attention=True),
            "reference default flags (A5): spectrogram tokens + 42 inter-stream synchrony tokens + cross-attention, loss_ce + loss_ibs_cls"),
+    "mm5": (dict(use_spectrogram=True, use_ibs=False, use_cross_attention=True),
+            "BASELINE configs[4]: three modalities -- gaze image (in-tree 2-D CNN branch) + EEG windows with STFT->2-D-CNN tokens, "
+            "cross-attention fusion -- joined by FuzzyGatingFusion on the logits; the whole multimodal step "
+            "(train_multimodal_fuzzy_fusion.py:395-543: fused + auxiliary CE + temperature regulariser, one global clip, "
+            "per-group AdamW, warm-up + cosine per step, dynamic loss scaling in fp16)"),
     "a5c32": (dict(use_spectrogram=True, use_ibs=True, use_robust_ibs=True, use_cross_attention=True, in_channels=32),
               "the reference's default yaml (4_Experiments/configs/dual_eeg_transformer.yaml:38-53): A5 flags at in_channels = 32 "
               "(S = 139, 1024-wide synchrony rows)"),
@@ -108,6 +113,132 @@ def cpu_baseline(kw, C, T, Bc=256, seconds_budget=30.0):
             "sample": f"oracle fwd+bwd+clip+AdamW, train mode, B={Bc} windows of the same synthetic workload, {n} timed steps after 1 warm-up"}
 
 
+ROUTES = {0: "gemm_nt_kernel", 1: "gemm_nt_wide_kernel", 2: "rs_gemm_kernel", 3: "gemm_nt_row_kernel", 4: "ffn_chain_kernel",
+          5: "gemm_nt_tall_kernel"}
+
+
+def roofline_from_probes(probes, nsteps_probed, dtype):
+    """Groups the HIP-event-bracketed eg_gemm_nt / eg_ffn_chain launches by the kernel that served them; returns the roofline of
+    the group with the most GPU time and the per-kernel list."""
+    peak = PEAK_F32_TFLOPS if dtype == "f32" else PEAK_BF16_TFLOPS
+    ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)
+    groups = {}
+    for a_, b_, f_, nb_, shape_, route_ in probes:
+        g_ = groups.setdefault(route_, {"n": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        g_["n"] += 1
+        g_["ms"] += a_.elapsed_time(b_)
+        g_["flops"] += f_
+        g_["bytes"] += nb_
+    by_kernel = [{"kernel": f"{ROUTES.get(r_, r_)}<{dtype}>", "launches_per_step": g_["n"] // nsteps_probed,
+                  "ms_per_step": round(g_["ms"] / nsteps_probed, 4), "launch_ms": round(g_["ms"] / g_["n"], 5),
+                  "GB/s": round(g_["bytes"] / g_["ms"] / 1e6, 1), "TFLOP/s": round(g_["flops"] / g_["ms"] / 1e9, 1)}
+                 for r_, g_ in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])]
+    r_, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    kms, flops, nbytes = dom["ms"] / dom["n"], dom["flops"] / dom["n"], dom["bytes"] / dom["n"]
+    tflops, gbs = flops / (kms * 1e-3) / 1e12, nbytes / (kms * 1e-3) / 1e9
+    hbm_bound = (flops / max(nbytes, 1.0)) < ridge
+    return {"kernel": f"{ROUTES.get(r_, r_)}<{dtype}> ({dom['n'] // nsteps_probed} launches per step)",
+            "bound": "hbm" if hbm_bound else "mfma", "achieved": round(gbs if hbm_bound else tflops, 2),
+            "peak": PEAK_HBM_GBS if hbm_bound else peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+            "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tflops / peak), 4), "traffic": None,
+            "launch_ms": round(kms, 5), "algorithmic_bytes_per_launch": round(nbytes),
+            "algorithmic_flops_per_launch": round(flops), "flop_per_byte": round(flops / max(nbytes, 1.0), 1),
+            "ridge_flop_per_byte": round(ridge, 1),
+            "mfma": {"achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4)},
+            "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)},
+            "eg_gemm_nt_by_kernel": by_kernel}
+
+
+def run_mm5(args, dev):
+    """BASELINE configs[4] on one MI355X: the multimodal logit-fusion step of train_multimodal_fuzzy_fusion.py at B = 256."""
+    import gc
+    from eyegaze_multimodal_amd.train_multimodal_fuzzy_fusion import build_from_config, synth_multimodal
+    B, C, T, F_, W_ = args.batch, 8, 1024, 64, 16
+    config = {"data": {"window_size": T, "num_classes": 3},
+              "eeg_encoder": {"in_channels": C, "use_spectrogram": True, "use_ibs": False, "use_cross_attention": True},
+              "gaze_encoder": {"d_model": 256}, "fusion": {"mode": "full"},
+              "training": {"encoder_learning_rate": 1e-4, "fusion_learning_rate": 1e-3, "weight_decay": 0.01, "max_grad_norm": 1.0,
+                           "epochs": 10, "steps_per_epoch": 1000, "warmup_epochs": 1, "fp16": args.dtype == "fp16",
+                           "compute_dtype": args.dtype}}
+    tr = build_from_config(config, dev)
+    img1, img2, x1, x2, y = (t_.to(dev) for t_ in synth_multimodal(B, C, T, F_, W_, 3, seed=1234))
+    probes = []
+    tr.train_step(img1, img2, x1, x2, y)                      # lazy workspaces, one-time kernel attributes
+    engines = tr._engines(B, T, F_, W_)
+    for e in engines:
+        e.probe_all = probes
+    tr.train_step(img1, img2, x1, x2, y)
+    launches_per_step = len(probes)
+    probes.clear()
+    n_probe_steps = min(8, max(2, args.steps // 5), args.steps)
+    stream0 = torch.cuda.current_stream(dev)
+    pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_probe_steps * launches_per_step)]
+    for a_, b_ in pool:
+        a_.record(stream0)
+        b_.record(stream0)
+    for e in engines:
+        e.probe_all, e.probe_pool = None, pool
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        tr.train_step(img1, img2, x1, x2, y)
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        for e in engines:
+            e.probe_all = probes if i < n_probe_steps else None
+        out = tr.train_step(img1, img2, x1, x2, y)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    loss = float(out["loss"])
+    assert loss == loss, "loss is NaN"
+    eeg = engines[0]
+    res = {"metric": "train samples/sec (gaze+EEG windows)", "value": round(B * args.steps / elapsed, 2), "unit": "samples/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"mm5: {WORKLOADS['mm5'][1]}", "batch_per_gpu": B, "global_batch": B, "C": C, "T": T,
+                      "image": [F_, W_], "seq_len": eeg.S, "d_model": 256, "layers": 6,
+                      "step": "fwd(image CNN + EEG, train, dropout) + fuzzy fusion + losses + bwd + global clip + per-group AdamW"
+                              + (" + loss scaling" if args.dtype == "fp16" else ""),
+                      "parallelism": "dp1", "final_loss": round(loss, 5)},
+           "roofline": roofline_from_probes(probes, n_probe_steps, args.dtype)}
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_mm5(tr, C, T, F_, W_, Bc=args.cpu_batch)
+    print(json.dumps(res), flush=True)
+
+
+def cpu_baseline_mm5(tr, C, T, F_, W_, Bc=256, seconds_budget=30.0):
+    """The CPU restatement of the multimodal step (oracle/multimodal_oracle.py::Stepper, kind 'port') on this host."""
+    import copy
+    from oracle import dual_eeg_oracle as O
+    from oracle.multimodal_oracle import Stepper
+    from eyegaze_multimodal_amd.train_multimodal_fuzzy_fusion import synth_multimodal
+    cores = min(16, len(os.sched_getaffinity(0)))
+    torch.set_num_threads(cores)
+    m = tr.model
+    gaze = copy.deepcopy(m.gaze_encoder).cpu().float()
+    eeg_sd = {k: v.detach().cpu().float().clone() if v.dtype.is_floating_point else v.detach().cpu().clone()
+              for k, v in m.eeg_encoder.state_dict().items()}
+    fus_sd = {k: v.detach().cpu().clone() for k, v in m.fusion.state_dict().items()}
+    cfg = O.ModelCfg(in_channels=C, num_classes=3, max_len=T // 4, use_spectrogram=True, use_ibs=False, use_cross_attention=True)
+    st = Stepper(gaze, cfg, eeg_sd, fus_sd, "full", tr.encoder_lr, tr.fusion_lr, tr.wd, tr.max_norm, tr.lams, tr.treg,
+                 tr.warmup_steps, tr.total_steps)
+    batch = synth_multimodal(Bc, C, T, F_, W_, 3, seed=1234)
+    tw = time.perf_counter()
+    st.step(*batch)
+    tw = time.perf_counter() - tw
+    t0, n = time.perf_counter(), 0
+    while n < 1 or (n < 3 and (time.perf_counter() - t0) + tw * 1.1 < seconds_budget):
+        st.step(*batch)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(Bc / dt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"multimodal oracle step (image CNN + EEG oracle + fuzzy fusion + clip + AdamW), eval-mode dropout, B={Bc}, "
+                      f"{n} timed steps after 1 warm-up"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,7 +246,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=256, help="windows pairs per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "f32"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "f32"],
+                    help="compute dtype (default bf16; fp16 for --workload mm5, as BASELINE configs[4] states)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay captured hipGraphs instead of eager launches")
     ap.add_argument("--eager", action="store_true", help="(default) accepted for compatibility")
@@ -130,6 +262,8 @@ def main():
     ap.add_argument("--plan-only", action="store_true",
                     help="rehearsal without a GPU: form the process group, report world/rank and exit (CPU test of the launcher)")
     args = ap.parse_args()
+    if args.dtype is None:
+        args.dtype = "fp16" if args.workload == "mm5" else "bf16"
 
     plans = plan_ranks(args.gpus, os.environ, share_gpu=args.share_gpu)
     if plans:                                  # launcher: nothing below runs in this process, the GPU stays untouched
@@ -174,6 +308,10 @@ def main():
     from eyegaze_multimodal_amd.data import randn_windows
     from eyegaze_multimodal_amd.ddp import GradAllReducer, broadcast_params, bucket_ranges
 
+    if args.workload == "mm5":
+        if world > 1:
+            raise SystemExit("--workload mm5 is a single-GPU measurement (the multimodal loop has no gradient reducer)")
+        return run_mm5(args, dev)
     T, B = 1024, args.batch
     kw, desc = WORKLOADS[args.workload]
     kw = dict(kw, num_classes=3)
