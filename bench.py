@@ -430,47 +430,22 @@ def main():
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
-        # eg_gemm_nt (every forward product -- strided convs, q/k/v/out, FFN, heads -- and every backward-data product) routes a
-        # launch to one of four kernels (eg_gemm_nt_route).  HIP events bracket EVERY launch of the timed region's first 8 steps
-        # on the launch stream; launches are grouped by the kernel they ran, and `roofline` describes the group with the most
-        # GPU time = the step's dominant kernel (rocprofv3 --kernel-trace --stats of this command under profiles/ agrees).
-        # Per launch (averaged over that kernel's launches of a step): algorithmic FLOPs = 2*M*N*K, algorithmic bytes = each
-        # distinct operand/output element once (Engine._gemm_bytes).  With d_model = 256 the products sit BELOW the ridge
-        # (FLOP/B < peak_flops/peak_bw), so the binding roofline is HBM; the MFMA fraction is reported beside it.
-        ROUTES = {0: "gemm_nt_kernel", 1: "gemm_nt_wide_kernel", 2: "rs_gemm_kernel", 3: "gemm_nt_row_kernel", 4: "ffn_chain_kernel",
-                  5: "gemm_nt_tall_kernel"}
-        peak = PEAK_F32_TFLOPS if args.dtype == "f32" else PEAK_BF16_TFLOPS
-        ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)
+        # eg_gemm_nt (every forward product -- strided convs, q/k/v/out, heads -- and every backward-data product) routes a launch
+        # to one of its kernels (eg_gemm_nt_route); eg_ffn_chain is the feed-forward pair.  HIP events bracket EVERY such launch
+        # of the timed region's first steps on the launch stream; launches are grouped by the kernel they ran, and `roofline`
+        # describes the group with the most GPU time = the step's dominant kernel (rocprofv3 --kernel-trace --stats of this command
+        # under profiles/ agrees).  Per launch (averaged over that kernel's launches of a step): algorithmic FLOPs = 2*M*N*K,
+        # algorithmic bytes = each distinct operand/output element once (Engine._gemm_bytes).  With d_model = 256 the products
+        # sit BELOW the ridge (FLOP/B < peak_flops/peak_bw), so the binding roofline is HBM; the MFMA fraction is reported beside it.
         nsteps_probed = (n_probe_steps if graphed is None else 4)
-        groups = {}
-        for a_, b_, f_, nb_, shape_, route_ in probes:
-            g_ = groups.setdefault(route_, {"n": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
-            g_["n"] += 1
-            g_["ms"] += a_.elapsed_time(b_)
-            g_["flops"] += f_
-            g_["bytes"] += nb_
-        by_kernel = []
-        for route_, g_ in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
-            by_kernel.append({"kernel": f"{ROUTES.get(route_, route_)}<{args.dtype}>", "launches_per_step": g_["n"] // nsteps_probed,
-                              "ms_per_step": round(g_["ms"] / nsteps_probed, 4), "launch_ms": round(g_["ms"] / g_["n"], 5),
-                              "GB/s": round(g_["bytes"] / g_["ms"] / 1e6, 1), "TFLOP/s": round(g_["flops"] / g_["ms"] / 1e9, 1)})
-        dom_route, dom = max(groups.items(), key=lambda kv: kv[1]["ms"]) if groups else (0, {"n": 1, "ms": 1.0, "flops": 0.0, "bytes": 0.0})
-        n_launch = dom["n"]
-        kms = dom["ms"] / n_launch
-        flops = dom["flops"] / n_launch
-        nbytes = dom["bytes"] / n_launch
-        tflops = flops / (kms * 1e-3) / 1e12
-        gbs = nbytes / (kms * 1e-3) / 1e9
-        hbm_bound = (flops / max(nbytes, 1.0)) < ridge
-        dom_name = ROUTES.get(dom_route, str(dom_route))
-        traffic = None
+        roof = roofline_from_probes(probes, nsteps_probed, args.dtype)
         # HBM traffic per launch of the dominant kernel comes from the separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE
-        # cannot share a pass, profiles/collect_r02.sh); the file names the kernel and commit state it was measured on.
+        # cannot share a pass, profiles/collect_r02.sh); the file names the kernel it was measured on.
         pmc = REPO / "profiles" / f"r02_pmc_{args.workload}_{args.dtype}.json"
         if pmc.exists() and B == 256:
             rec = json.loads(pmc.read_text())
-            if rec.get("kernel", "").startswith(dom_name):
-                traffic = rec.get("hbm_bytes_per_launch")
+            if roof["kernel"].startswith(rec.get("kernel", "?")):
+                roof["traffic"] = rec.get("hbm_bytes_per_launch")
         per_step = len(probes) // nsteps_probed
         if args.probe_dump:
             rows = []
@@ -481,17 +456,6 @@ def main():
                 rows.append({"launch": j, "kernel": ROUTES.get(route_, route_), "M": shape[0], "N": shape[1], "K": shape[2],
                              "us": round(us, 2), "tflops": round(f / us / 1e6, 1), "gbs": round(nb / us / 1e3, 1)})
             Path(args.probe_dump).write_text(json.dumps(rows, indent=0))
-        roof = {"kernel": f"{dom_name}<{args.dtype}> ({n_launch // nsteps_probed} launches per step)",
-                "bound": "hbm" if hbm_bound else "mfma",
-                "achieved": round(gbs if hbm_bound else tflops, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
-                "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tflops / peak), 4), "traffic": traffic,
-                "launch_ms": round(kms, 5), "algorithmic_bytes_per_launch": round(nbytes),
-                "algorithmic_flops_per_launch": round(flops), "flop_per_byte": round(flops / max(nbytes, 1.0), 1),
-                "ridge_flop_per_byte": round(ridge, 1),
-                "mfma": {"achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4)},
-                "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)},
-                "eg_gemm_nt_by_kernel": by_kernel}
         out = {
             "metric": "train samples/sec (gaze+EEG windows)", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
