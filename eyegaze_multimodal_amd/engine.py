@@ -533,16 +533,29 @@ class Engine:
                       ([pre + "mha.q_proj", pre + "mha.k_proj", pre + "mha.v_proj"], f"dqkv{l}", f"x{l}", 3 * d, d, 3 * d),
                       ([pre + "ffn.linear2"], f"dYf{l}", f"hff{l}", d, F, d),
                       ([pre + "ffn.linear1"], f"dh{l}", f"y1_{l}", F, d, F)]
-        for names, _, _, N, K, _ in probs:      # (weight, bias) pairs must sit back to back in the flat buffer
+        def packed(names, N, K):                 # (weight, bias) pairs must sit back to back in the flat buffer
             P = N // len(names)
             base = fp.offsets[names[0] + ".weight"]
-            if not all(fp.offsets[n + ".weight"] == base + i * (P * K + P) and fp.offsets[n + ".bias"] == base + i * (P * K + P) + P * K
-                       for i, n in enumerate(names)):
-                return None
+            return all(fp.offsets[n + ".weight"] == base + i * (P * K + P) and fp.offsets[n + ".bias"] == base + i * (P * K + P) + P * K
+                       for i, n in enumerate(names))
+        if not all(packed(names, N, K) for names, _, _, N, K, _ in probs):
+            return None
+        # the two weight gradients of the cross-attention block ride in the same launch (their own dY buffers, as the layers have)
+        cx = "cross_attn.cross_attn."
+        cross = [([cx + "out_proj"], "dYo_x", "ctxx", d, d, d),
+                 ([cx + "q_proj", cx + "k_proj", cx + "v_proj"], "dqkv_x", "zn", 3 * d, d, 3 * d)]
+        self._wg_cross = (cfg.use_cross_attention and os.environ.get("EYEGAZE_WGRAD_CROSS", "1") != "0"
+                          and all(packed(names, N, K) for names, _, _, N, K, _ in cross))
+        ncross = 0
+        if self._wg_cross:
+            probs += cross
+            ncross = len(cross)
         g = self.g
         for l in range(cfg.num_layers):
             g[f"dYo{l}"], g[f"dYf{l}"] = self._t(M, d), self._t(M, d)
             g[f"dqkv{l}"], g[f"dh{l}"] = self._t(M, 3 * d), self._t(M, F)
+        if self._wg_cross:
+            g["dYo_x"], g["dqkv_x"] = self._t(M, d), self._t(M, 3 * d)
         # 16-bit dtypes: 256 x 256 tiles, one 512-thread workgroup per CU (72 tiles x 3 row splits = 216 blocks, one round);
         # otherwise 128 x 128 tiles, three 256-thread workgroups per CU (288 tiles x 5 splits)
         big = (self.dtype != EG_F32 and os.environ.get("EYEGAZE_TN256", "1") != "0"
@@ -565,11 +578,14 @@ class Engine:
             offs.append(off)
             off += splits * (N * K + N)
 
-        def tables(layers):
-            """TN problem table + reduce table (weights, biases and the deferred LayerNorm gain / bias partials) of `layers`;
-            block ranges are relative to the tables' own launches.  Which launch a product rides in changes neither its split
-            nor its summation order, so every piece arrangement yields bit-identical gradients."""
+        def tables(layers, with_cross=False):
+            """TN problem table + reduce table (weights, biases and the deferred LayerNorm gain / bias partials) of `layers`
+            (+ the cross-attention block's two products); block ranges are relative to the tables' own launches.  Which launch
+            a product rides in changes neither its split nor its summation order, so every piece arrangement yields bit-identical
+            gradients."""
             sel = [4 * l + j for l in layers for j in range(4)]
+            if with_cross:
+                sel += [4 * cfg.num_layers + j for j in range(ncross)]
             lns = [e for l in layers for e in ln_of[l]]
             tp = (L.TNProblem * len(sel))()
             rt = (L.ReduceEntry * (len(sel) + len(lns)))()
@@ -594,7 +610,7 @@ class Engine:
             return dict(tp=dev(tp), rt=dev(rt), n=len(sel), nr=len(sel) + len(lns), blocks=blk, rblocks=rblk, layers=list(layers))
 
         Lr = cfg.num_layers
-        whole = tables(range(Lr))
+        whole = tables(range(Lr), with_cross=True)
         # the same problems as per-layer tables: used when the weight gradients of a layer are launched on the side stream as
         # soon as that layer's backward-data chain has produced them (EYEGAZE_WGRAD_OVERLAP=1)
         per_layer = []
@@ -604,8 +620,9 @@ class Engine:
         # data parallel: two pieces, so the gradient buckets of layers L-1 .. L/2 start their all-reduce while layers L/2-1 .. 0
         # are still in backward (one piece would hold every encoder bucket back until backward has finished)
         h = Lr // 2
-        pieces = [tables(range(h, Lr)), tables(range(0, h))] if Lr >= 2 else [whole]
-        self._wg_plan = dict(whole, splits=splits, per_layer=per_layer, pieces=pieces, split_layer=h,
+        pieces = [tables(range(h, Lr), with_cross=True), tables(range(0, h))] if Lr >= 2 else [whole]
+        cross_only = tables([], with_cross=True) if ncross else None      # (side-stream mode: the cross block's pair on its own)
+        self._wg_plan = dict(whole, splits=splits, per_layer=per_layer, pieces=pieces, split_layer=h, cross_only=cross_only,
                              entry="eg_gemm_tn_grouped256" if big else "eg_gemm_tn_grouped")
         return self._wg_plan
 
@@ -614,6 +631,9 @@ class Engine:
         pl = self._wg_plan if piece is None else piece
         if self._wg_side is not None:          # the per-layer launches are already queued on the side stream: join it
             torch.cuda.current_stream(self.device).wait_stream(self._wg_side)
+            co = self._wg_plan.get("cross_only")
+            if co is not None:
+                call(self._wg_plan["entry"], ptr(co["tp"]), co["n"], co["blocks"], self.M, self._wg_plan["splits"], self.dtype, self.stream)
         else:
             call(self._wg_plan["entry"], ptr(pl["tp"]), pl["n"], pl["blocks"], self.M, self._wg_plan["splits"], self.dtype, self.stream)
         call("eg_reduce_table", ptr(pl["rt"]), pl["nr"], pl["rblocks"], self.stream)
@@ -929,13 +949,22 @@ class Engine:
                 self._ln_b_finish(ln_next)
 
         has_drop = p > 0
+        gx = False
         if cfg.use_cross_attention:
             xs = _layer_sites(Lr)
-            self.ln_bwd(dz, a["rx"], a["stx"], "cross_attn.norm", g["dr"], g["drm"] if has_drop else None, d1=(p, xs["drop1"]))
-            drm = g["drm"] if has_drop else g["dr"]
-            attn_block_bwd("cross_attn.cross_attn.", "x", a["zn"], g["dr"], drm, B, xs["attn"], other, g["dqkv"], False)
+            gx = grouped and self._wg_cross                     # its weight gradients ride in the grouped launch
+            drm = g["dYo_x"] if gx else (g["drm"] if has_drop else g["dr"])
+            if has_drop:
+                self.ln_bwd(dz, a["rx"], a["stx"], "cross_attn.norm", g["dr"], drm, d1=(p, xs["drop1"]))
+                drx = g["dr"]
+            else:
+                self.ln_bwd(dz, a["rx"], a["stx"], "cross_attn.norm", drm, None)
+                drx = drm
+            attn_block_bwd("cross_attn.cross_attn.", "x", a["zn"], drx, drm, B, xs["attn"], other,
+                           g["dqkv_x"] if gx else g["dqkv"], gx)
             dz, other = other, dz
-            seg("cross")
+            if not gx:
+                seg("cross")
         # final encoder norm (A:328)
         self.ln_bwd(dz, a[f"x{Lr}"], a["stf"], "encoder.norm", other)
         dz, other = other, dz
@@ -1004,6 +1033,8 @@ class Engine:
                 # upper half of the encoder: its weight gradients are complete -> reduce them now, hand the buckets to the
                 # all-reduce while the lower layers' backward-data chain keeps the compute stream busy
                 self._wgrad_group_launch(self._wg_plan["pieces"][0])
+                if gx:
+                    seg("cross")
                 for ll in reversed(self._wg_plan["pieces"][0]["layers"]):
                     seg(f"layer{ll}")
         if grouped:
@@ -1013,6 +1044,8 @@ class Engine:
                     seg(f"layer{ll}")
             else:
                 self._wgrad_group_launch()
+                if gx:
+                    seg("cross")
                 for l in reversed(range(Lr)):
                     seg(f"layer{l}")
         dseq = dz
