@@ -64,7 +64,7 @@ template <typename T> __device__ __forceinline__ u32x2 f_pack4(const float v[4])
   return o;
 }
 
-template <typename T, int GATE, int BOUT, int LNF>
+template <typename T, int GATE, int BOUT, int LNF, int P2>
 __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   typedef typename H16<T>::frag frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -108,8 +108,10 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   };
 #pragma unroll
   for (int s = 0; s < 4; ++s) req_w1(0, s, s);
+  if (P2) {
 #pragma unroll
-  for (int s = 0; s < 2; ++s) req_w2(0, s, s);
+    for (int s = 0; s < 2; ++s) req_w2(0, s, s);
+  }
 
   f32x4 acc2[5][4];
 #pragma unroll
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   //      chunks' 128-B lines here, where the wave waits for its HBM-resident A rows anyway: by the time chunk 1 is needed the
   //      lines sit in the memory-side cache, one XCD's L2 miss away. ----
   uint32_t touched = 0;
-  if (wn < 2) {
+  if (wn < (P2 ? 2 : 1)) {
     const char* wb = (const char*)(wn == 0 ? p.W1 : p.W2);
     const int lines = p.F * FD * 2 / 128;                    // per matrix
     const int per = (lines + gridDim.x - 1) / gridDim.x;
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
     }
 
     // ---- product 2: acc2[i][j] += sum_h W2[col][h] * H[row][h] over the chunk's 128 hidden columns ----
+    if (P2) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       frag hf[5];
@@ -260,7 +263,9 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
       if (s < 2) req_w2(c, s + 2, s & 1);
       else if (c + 1 < nch) req_w2(c + 1, s - 2, s & 1);
     }
+    }
   }
+  if (!P2) return;          // product 1 only (e.g. the fused q|k|v projection): H is the result
   __syncthreads();          // every wave has left the chunk buffers: they become the fp32 image of the final epilogue
 
   // ---- epilogue 2: per 16-row tile through a wave-private fp32 image [16][68]; a lane then owns 16 consecutive columns of a row ----
@@ -388,18 +393,19 @@ static int ffn_launch(const eg_ffn_desc* d, hipStream_t s) {
   p.dc2 = make_drop(d->drop_c2_p, d->drop_c2_site);
   p.gate_scale = d->gate_scale == 0.f ? 1.0f : d->gate_scale;
   const dim3 grid((d->M + FR - 1) / FR);
-#define FFN_LAUNCH(G_, B_, L_)                                                                                                 \
+#define FFN_LAUNCH(G_, B_, L_, P_)                                                                                                 \
   do {                                                                                                                 \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      (void)hipFuncSetAttribute((const void*)ffn_chain_kernel<T, G_, B_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS); \
+      (void)hipFuncSetAttribute((const void*)ffn_chain_kernel<T, G_, B_, L_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS); \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((ffn_chain_kernel<T, G_, B_, L_>), grid, dim3(256), F_LDS, s, p);                                                        \
+    hipLaunchKernelGGL((ffn_chain_kernel<T, G_, B_, L_, P_>), grid, dim3(256), F_LDS, s, p);                                                        \
   } while (0)
-  if (d->gate_bits_in) FFN_LAUNCH(2, 0, 0); else if (d->gate) FFN_LAUNCH(1, 0, 0);
-  else if (d->ln_out) { if (d->gate_bits_out) FFN_LAUNCH(0, 1, 1); else FFN_LAUNCH(0, 0, 1); }
-  else if (d->gate_bits_out) FFN_LAUNCH(0, 1, 0); else FFN_LAUNCH(0, 0, 0);
+  if (!d->W2) FFN_LAUNCH(0, 0, 0, 0);
+  else if (d->gate_bits_in) FFN_LAUNCH(2, 0, 0, 1); else if (d->gate) FFN_LAUNCH(1, 0, 0, 1);
+  else if (d->ln_out) { if (d->gate_bits_out) FFN_LAUNCH(0, 1, 1, 1); else FFN_LAUNCH(0, 0, 1, 1); }
+  else if (d->gate_bits_out) FFN_LAUNCH(0, 1, 0, 1); else FFN_LAUNCH(0, 0, 0, 1);
 #undef FFN_LAUNCH
   EG_LAUNCH_CHECK("ffn_chain");
   return 0;
@@ -408,11 +414,14 @@ static int ffn_launch(const eg_ffn_desc* d, hipStream_t s) {
 }  // namespace
 
 extern "C" int eg_ffn_chain(const eg_ffn_desc* d, void* stream) {
-  EG_CHECK(d && d->A && d->W1 && d->W2 && d->H && d->C, "eg_ffn_chain: null operand");
+  EG_CHECK(d && d->A && d->W1 && d->H, "eg_ffn_chain: null operand");
+  EG_CHECK((d->W2 != nullptr) == (d->C != nullptr), "eg_ffn_chain: W2 and C go together (both NULL: product 1 only)");
+  EG_CHECK(d->W2 || !(d->gate || d->gate_bits_in || d->gate_bits_out || d->ln_out || d->residual),
+           "eg_ffn_chain: the product-1-only form takes bias1 / act1 / drop_h only");
   EG_CHECK(d->dtype == EG_BF16 || d->dtype == EG_F16, "eg_ffn_chain: 16-bit compute dtypes only (got %d)", d->dtype);
   EG_CHECK(d->M > 0 && d->F > 0 && d->F % FC == 0, "eg_ffn_chain: M=%d, F=%d (F must be a multiple of %d)", d->M, d->F, FC);
   EG_CHECK(d->act1 == EG_ACT_NONE || d->act1 == EG_ACT_RELU, "eg_ffn_chain: act1 %d", d->act1);
-  EG_CHECK(d->lda >= FD && d->ldc >= FD && d->ldh >= d->F && d->lda % 8 == 0 && d->ldc % 8 == 0 && d->ldh % 8 == 0,
+  EG_CHECK(d->lda >= FD && (!d->C || d->ldc >= FD) && d->ldh >= d->F && d->lda % 8 == 0 && d->ldc % 8 == 0 && d->ldh % 8 == 0,
            "eg_ffn_chain: row strides must be 16-B multiples covering the rows");
   EG_CHECK(!d->gate || (d->ldg >= d->F && d->ldg % 4 == 0), "eg_ffn_chain: gate stride");
   EG_CHECK(!(d->gate_bits_out && (d->gate_bits_in || d->gate)), "eg_ffn_chain: a launch either writes gate bits or applies a gate");

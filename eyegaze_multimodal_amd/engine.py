@@ -154,6 +154,9 @@ class Engine:
         # LayerNorm launch (3.795 vs 3.790 ms / step: the epilogue's extra 17 MB store and three barriers cost what the 8.5 us
         # launch cost), so opt-in
         self.ffn_ln = os.environ.get("EYEGAZE_FFN_LN", "0") == "1"
+        # q|k|v through eg_ffn_chain's product-1-only form: bit-identical, measured EQUAL to the row-stream GEMM (29 vs 28 us per
+        # launch, step 3.716 vs 3.703 ms), so opt-in
+        self.qkv_chain = os.environ.get("EYEGAZE_QKV_CHAIN", "0") == "1"
         self.cus = torch.cuda.get_device_properties(device).multi_processor_count if device.type == "cuda" else 256
         # feed-forward pair as one launch (csrc/ffn.hip): 16-bit compute dtypes, d_model == 256, d_ff a multiple of 128
         self.fuse_ffn = (dtype != EG_F32 and cfg.d_model == 256 and cfg.d_ff % 128 == 0 and not self.fuse_ln
@@ -199,6 +202,8 @@ class Engine:
             w[f"o{l}"] = self._t(d, d)
             w[f"oT{l}"] = self._t(d, d)
             w[f"bqkv{l}"] = self._t(3 * d, dtype=f32)
+            if self.fuse_ffn and self.qkv_chain:      # q|k|v weights in eg_ffn_chain's fragment order (product-1-only form)
+                w[f"qkvf{l}"] = self._t(3 * d * d)
             if l != "x":
                 w[f"w1{l}"] = self._t(F, d)
                 w[f"w1T{l}"] = self._t(d, F)
@@ -353,6 +358,15 @@ class Engine:
         if probe:
             probe[1].record(torch.cuda.current_stream(self.device))
 
+    def qkv_proj(self, x, l):
+        """q|k|v = x W^T + b (A:203-205), fused over the three projections: eg_ffn_chain's product-1-only form (the A tile resident
+        in LDS, fragment-ordered weights straight to registers) when available, else the row-stream GEMM"""
+        M, d = self.M, self.cfg.d_model
+        if self.fuse_ffn and self.qkv_chain:
+            self.ffn(ptr(x), ptr(self.w[f"qkvf{l}"]), 0, ptr(self.a[f"qkv{l}"]), 0, M, 3 * d, bias1=ptr(self.w[f"bqkv{l}"]))
+        else:
+            self.gemm(ptr(x), ptr(self.w[f"qkv{l}"]), ptr(self.a[f"qkv{l}"]), M, 3 * d, d, bias=ptr(self.w[f"bqkv{l}"]))
+
     def _probe_pair(self):
         """A (start, end) event pair for a timed launch: from bench.py's pre-created pool when there is one -- creating a
         hipEvent costs the host far more than recording one, and fresh events inside the timed region made short runs host-bound."""
@@ -366,7 +380,7 @@ class Engine:
         """eg_ffn_chain: H = epi1(A W1^T), C = epi2(H W2^T) in one launch (weights in fragment order)."""
         d = self.cfg.d_model
         dsc = L.FfnDesc()
-        dsc.A, dsc.W1, dsc.W2, dsc.H, dsc.C = A, W1f, W2f, H, Cout
+        dsc.A, dsc.W1, dsc.W2, dsc.H, dsc.C = A, W1f, W2f or None, H, Cout or None
         dsc.bias1, dsc.bias2, dsc.gate, dsc.residual = bias1 or None, bias2 or None, gate or None, residual or None
         dsc.gate_bits_out, dsc.gate_bits_in = bits_out or None, bits_in or None
         dsc.state = self.st_ptr
@@ -384,7 +398,9 @@ class Engine:
             es = self.es
             nbytes = es * (M * d * (2 + (1 if residual and residual != A else 0) + (1 if ln else 0)) + M * F * (1 + (1 if gate else 0)) + 2 * F * d) \
                 + (M * F // 8 if (bits_out or bits_in) else 0) + 4 * (F + d)
-            self.probe_all.append((probe[0], probe[1], 4.0 * M * F * d, float(nbytes), (M, F, d), 4))
+            if not W2f:                     # product-1-only form: one K = d product
+                nbytes = es * (M * d + M * F + F * d) + 4 * F
+            self.probe_all.append((probe[0], probe[1], (4.0 if W2f else 2.0) * M * F * d, float(nbytes), (M, F, d), 4 if W2f else 7))
             probe[0].record(torch.cuda.current_stream(self.device))
         call("eg_ffn_chain", C.byref(dsc), self.stream)
         if probe:
@@ -750,6 +766,8 @@ class Engine:
                 self.p_cast(fp.p_ptr(f"{pre}{n}.weight"), ptr(w[f"qkv{l}"]) + i * d * d * self.es, d * d)
                 self.p_transpose(fp.p_ptr(f"{pre}{n}.weight"), ptr(w[f"qkvT{l}"]) + i * d * self.es, d, d, 3 * d)
                 self.p_copy(fp.p_ptr(f"{pre}{n}.bias"), ptr(w[f"bqkv{l}"]) + 4 * i * d, d)
+                if self.fuse_ffn and self.qkv_chain:  # projection i = hidden chunks 2i, 2i+1 of the [768, 256] role-1 matrix
+                    self.p_frag(fp.p_ptr(f"{pre}{n}.weight"), ptr(w[f"qkvf{l}"]) + i * d * d * self.es, d, d, 3)
             self.p_cast(fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"o{l}"]), d * d)
             self.p_transpose(fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"oT{l}"]), d, d, d)
 
@@ -811,7 +829,7 @@ class Engine:
         for l in range(cfg.num_layers):
             pre, sites = f"encoder.layers.{l}.", _layer_sites(l)
             x = a[f"x{l}"]
-            self.gemm(ptr(x), ptr(w[f"qkv{l}"]), ptr(a[f"qkv{l}"]), M, 3 * d, d, bias=ptr(w[f"bqkv{l}"]))
+            self.qkv_proj(x, l)
             call("eg_attention_fwd", ptr(a[f"qkv{l}"]), ptr(a[f"ctx{l}"]), ptr(a[f"lse{l}"]), NB, S, H, 0, self.dtype, p,
                  sites["attn"], self.st_ptr, st)
             self._probs_hook(self.model.encoder.layers[l].mha.dropout, a[f"qkv{l}"], a[f"lse{l}"], 0)
@@ -840,7 +858,7 @@ class Engine:
         if cfg.use_cross_attention:
             # D:966-974: both directions in one launch each (kv_shift = B pairs window b with b+B)
             xs = _layer_sites(Lr)
-            self.gemm(ptr(z), ptr(w["qkvx"]), ptr(a["qkvx"]), M, 3 * d, d, bias=ptr(w["bqkvx"]))
+            self.qkv_proj(z, "x")
             call("eg_attention_fwd", ptr(a["qkvx"]), ptr(a["ctxx"]), ptr(a["lsex"]), NB, S, H, B, self.dtype, p, xs["attn"],
                  self.st_ptr, st)
             self._probs_hook(self.model.cross_attn.cross_attn.dropout, a["qkvx"], a["lsex"], B)

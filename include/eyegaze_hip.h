@@ -183,6 +183,8 @@ int eg_frag_order_rows(const void* src, void* dst, int K, int ldw, int count, vo
  *   scaled by gate_scale), W2 = linear1^T, residual = the gradient arriving on the skip path.
  *   Bit-identical to the two eg_gemm_nt launches it replaces (same MFMA chains, epilogue order and dropout indices m*N + n);
  *   the hidden rows cross HBM once (the stored H) instead of three times.  16-bit dtypes, F % 128 == 0, strides in elements.
+ *   W2 == C == NULL: product 1 only, H = drop_h(act1(A * W1^T + bias1)) -- a K = 256 product on the same data path (the fused
+ *   q|k|v projection, A:203-205, with F = 768).
  * ------------------------------------------------------------------------------------------- */
 typedef struct eg_ffn_desc {
   const void* A;        /* [M, 256], row stride lda */

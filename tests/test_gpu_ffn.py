@@ -212,3 +212,31 @@ def test_ffn_chain_layernorm_epilogue_matches_the_layernorm_kernel(M, dtype):
     err = (y.float() - y_ref.float()).abs()
     assert float((err / (y_ref.float().abs() + 1.0)).max()) <= 2 * ulp
     assert float((err > 0).float().mean()) < 0.02          # only rounding-boundary cases differ
+
+
+@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("M,F,act,p", [(33280, 768, 0, 0.0), (1037, 768, 0, 0.0), (7, 128, 1, 0.1), (4160, 1024, 1, 0.1)])
+def test_product_one_only_form_is_bit_identical_to_gemm_nt(M, F, act, p, dtype):
+    """W2 == C == NULL: eg_ffn_chain is a K = 256 product (the fused q|k|v projection runs on it); same chains, same epilogue."""
+    t = TDT[dtype]
+    o = operands(M, F, dtype, seed=31)
+    ref = torch.full((M, F), 7.0, device=DEV, dtype=t)
+    d = GemmDesc()
+    d.A, d.W, d.C, d.bias, d.state = ptr(o["A"]), ptr(o["W1"]), ptr(ref), ptr(o["b1"]), ptr(o["st"])
+    d.a, d.c = rowmap(D), rowmap(F)
+    d.r, d.p = d.c, d.c
+    d.M, d.N, d.K, d.ldw, d.dtype, d.act = M, F, D, D, dtype, act
+    d.drop1_p, d.drop1_site = p, 21
+    call("eg_gemm_nt", C.byref(d), 0)
+    H = torch.full((M, F), 7.0, device=DEV, dtype=t)
+    f = FfnDesc()
+    w1f = frag_pack(o["W1"], 3, dtype)
+    f.A, f.W1, f.H, f.bias1, f.state = ptr(o["A"]), ptr(w1f), ptr(H), ptr(o["b1"]), ptr(o["st"])
+    f.lda, f.ldh, f.M, f.F, f.dtype, f.act1 = D, F, M, F, dtype, act
+    f.drop_h_p, f.drop_h_site = p, 21
+    call("eg_ffn_chain", C.byref(f), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(H, ref), float((H.float() - ref.float()).abs().max())
+    f.C = ptr(ref)                      # C without W2: refused
+    with pytest.raises(L.EgError):
+        call("eg_ffn_chain", C.byref(f), 0)
