@@ -134,6 +134,20 @@ def roofline_from_probes(probes, nsteps_probed, dtype):
                   "GB/s": round(g_["bytes"] / g_["ms"] / 1e6, 1), "TFLOP/s": round(g_["flops"] / g_["ms"] / 1e9, 1)}
                  for r_, g_ in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])]
     r_, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    # the dominant kernel's launches split by the roofline that binds each (its products straddle the ridge: the encoder's
+    # K <= 1024 products sit below it, the strided convolutions above): the aggregate fraction mixes the two
+    split = {"hbm": {"n": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}, "mfma": {"n": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}}
+    for a_, b_, f_, nb_, shape_, route_ in probes:
+        if route_ == r_:
+            c_ = split["hbm" if f_ / max(nb_, 1.0) < ridge else "mfma"]
+            c_["n"] += 1
+            c_["ms"] += a_.elapsed_time(b_)
+            c_["flops"] += f_
+            c_["bytes"] += nb_
+    by_bound = [{"bound": k_, "launches_per_step": c_["n"] // nsteps_probed, "ms_per_step": round(c_["ms"] / nsteps_probed, 4),
+                 "GB/s": round(c_["bytes"] / c_["ms"] / 1e6, 1), "TFLOP/s": round(c_["flops"] / c_["ms"] / 1e9, 1),
+                 "frac": round((c_["bytes"] / c_["ms"] / 1e6 / PEAK_HBM_GBS) if k_ == "hbm" else (c_["flops"] / c_["ms"] / 1e9 / peak), 4)}
+                for k_, c_ in split.items() if c_["n"]]
     kms, flops, nbytes = dom["ms"] / dom["n"], dom["flops"] / dom["n"], dom["bytes"] / dom["n"]
     tflops, gbs = flops / (kms * 1e-3) / 1e12, nbytes / (kms * 1e-3) / 1e9
     hbm_bound = (flops / max(nbytes, 1.0)) < ridge
@@ -146,7 +160,7 @@ def roofline_from_probes(probes, nsteps_probed, dtype):
             "ridge_flop_per_byte": round(ridge, 1),
             "mfma": {"achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4)},
             "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)},
-            "eg_gemm_nt_by_kernel": by_kernel}
+            "dominant_by_bound": by_bound, "eg_gemm_nt_by_kernel": by_kernel}
 
 
 def run_mm5(args, dev):
