@@ -659,3 +659,20 @@ def test_reduce_table_wide_and_narrow_entries():
         ref = p[:, :n].double().sum(0)
         torch.testing.assert_close(o[:n].double().cpu(), ref.cpu(), rtol=1e-6, atol=1e-5)
         assert float(o[n:].min()) == 7.0          # nothing written past n
+
+
+@pytest.mark.parametrize("knob", ["0", "2"], ids=["two_pass_everywhere", "single_sweep_up_to_128"])
+def test_attention_backward_variants_not_selected_by_default(knob):
+    """The attention backward has two kernels (two-pass; single sweep, default for S <= 96).  The selection is read once per
+    process, so the non-default pairings -- two-pass at S <= 96, single sweep at 96 < S <= 128 -- are exercised by re-running
+    this file's attention tests in a child process with EYEGAZE_ATTN_BWD1 set."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, EYEGAZE_ATTN_BWD1=knob)
+    r = subprocess.run([sys.executable, "-m", "pytest", str(Path(__file__)), "-q", "-x", "-m", "gpu", "-k",
+                        "attention and not variants_not_selected"], env=env, cwd=str(repo), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
