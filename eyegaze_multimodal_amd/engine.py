@@ -579,7 +579,14 @@ class Engine:
         splits = int(os.environ.get("EYEGAZE_GROUP_SPLITS256", "3")) if big else self.GROUP_SPLITS
         tile = 256 if big else 128
         total = sum(N * K + N for _, _, _, N, K, _ in probs)
-        g["wg_partial"] = self._t(splits * total, dtype=torch.float32)
+        # data-parallel runs cut the launch in two pieces; with 256 x 256 tiles a piece has ~40 tiles, so it takes twice the
+        # row splits to fill the chip (240 / 216 blocks) -- with the whole launch's 3 splits each piece ran on 45 % of the CUs
+        # and the pair cost 0.42 ms more than the single launch
+        Lr_ = cfg.num_layers
+        piece_tiles = ((Lr_ - Lr_ // 2) * 12 + (4 if self._wg_cross else 0)) if big else 0
+        splits_p = max(splits, self.cus // piece_tiles) if big and piece_tiles else splits
+        smax = max(splits, splits_p)
+        g["wg_partial"] = self._t(smax * total, dtype=torch.float32)
         ln_names = [f"encoder.layers.{l}.{n}" for l in range(cfg.num_layers) for n in ("ln1", "ln2")]
         if not all(fp.offsets[n + ".bias"] == fp.offsets[n + ".weight"] + d for n in ln_names):
             return None
@@ -592,13 +599,14 @@ class Engine:
         offs, off = [], 0
         for names, dyn, xn, N, K, ldy in probs:
             offs.append(off)
-            off += splits * (N * K + N)
+            off += smax * (N * K + N)
 
-        def tables(layers, with_cross=False):
+        def tables(layers, with_cross=False, nsplit=None):
             """TN problem table + reduce table (weights, biases and the deferred LayerNorm gain / bias partials) of `layers`
             (+ the cross-attention block's two products); block ranges are relative to the tables' own launches.  Which launch
             a product rides in changes neither its split nor its summation order, so every piece arrangement yields bit-identical
             gradients."""
+            nsplit = nsplit or splits
             sel = [4 * l + j for l in layers for j in range(4)]
             if with_cross:
                 sel += [4 * cfg.num_layers + j for j in range(ncross)]
@@ -612,9 +620,9 @@ class Engine:
                 base = ptr(g["wg_partial"]) + 4 * offs[pi]
                 e.dY, e.X, e.partial = ptr(g[dyn]), ptr(self.a[xn]), base
                 e.ldy, e.ldx, e.N, e.K, e.part_rows, e.has_bias, e.blk0 = ldy, K, N, K, N // len(names), 1, blk
-                blk += ((N + tile - 1) // tile) * ((K + tile - 1) // tile) * splits
-                r.partial, r.out, r.n, r.stride, r.splits, r.blk0 = base, fp.g_ptr(names[0] + ".weight"), slab, slab, splits, rblk
-                rblk += _reduce_blocks(slab, splits)
+                blk += ((N + tile - 1) // tile) * ((K + tile - 1) // tile) * nsplit
+                r.partial, r.out, r.n, r.stride, r.splits, r.blk0 = base, fp.g_ptr(names[0] + ".weight"), slab, slab, nsplit, rblk
+                rblk += _reduce_blocks(slab, nsplit)
             for k, (i, n) in enumerate(lns):   # deferred LayerNorm gain / bias partials ride in the same reduce launch
                 r = rt[len(sel) + k]
                 r.partial, r.out = ptr(g["lnpart_all"]) + 4 * i * self.ln_nblk_cap * 2 * d, fp.g_ptr(n + ".weight")
@@ -623,7 +631,8 @@ class Engine:
                 fused = self.fuse_ln and not n.endswith(f"layers.{cfg.num_layers - 1}.ln2")
                 r.n, r.stride, r.splits, r.blk0 = 2 * d, 2 * d, ((M + 63) // 64 if fused else self.LN_BLOCKS), rblk
                 rblk += _reduce_blocks(2 * d, r.splits)
-            return dict(tp=dev(tp), rt=dev(rt), n=len(sel), nr=len(sel) + len(lns), blocks=blk, rblocks=rblk, layers=list(layers))
+            return dict(tp=dev(tp), rt=dev(rt), n=len(sel), nr=len(sel) + len(lns), blocks=blk, rblocks=rblk, layers=list(layers),
+                        splits=nsplit)
 
         Lr = cfg.num_layers
         whole = tables(range(Lr), with_cross=True)
@@ -636,7 +645,8 @@ class Engine:
         # data parallel: two pieces, so the gradient buckets of layers L-1 .. L/2 start their all-reduce while layers L/2-1 .. 0
         # are still in backward (one piece would hold every encoder bucket back until backward has finished)
         h = Lr // 2
-        pieces = [tables(range(h, Lr), with_cross=True), tables(range(0, h))] if Lr >= 2 else [whole]
+        pieces = ([tables(range(h, Lr), with_cross=True, nsplit=splits_p), tables(range(0, h), nsplit=splits_p)]
+                  if Lr >= 2 else [whole])
         cross_only = tables([], with_cross=True) if ncross else None      # (side-stream mode: the cross block's pair on its own)
         self._wg_plan = dict(whole, splits=splits, per_layer=per_layer, pieces=pieces, split_layer=h, cross_only=cross_only,
                              entry="eg_gemm_tn_grouped256" if big else "eg_gemm_tn_grouped")
@@ -651,7 +661,7 @@ class Engine:
             if co is not None:
                 call(self._wg_plan["entry"], ptr(co["tp"]), co["n"], co["blocks"], self.M, self._wg_plan["splits"], self.dtype, self.stream)
         else:
-            call(self._wg_plan["entry"], ptr(pl["tp"]), pl["n"], pl["blocks"], self.M, self._wg_plan["splits"], self.dtype, self.stream)
+            call(self._wg_plan["entry"], ptr(pl["tp"]), pl["n"], pl["blocks"], self.M, pl["splits"], self.dtype, self.stream)
         call("eg_reduce_table", ptr(pl["rt"]), pl["nr"], pl["rblocks"], self.stream)
 
     def _wgrad_layer_async(self, l: int):

