@@ -2,7 +2,7 @@
 summed with torch.distributed all-reduce (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in CPU tests).
 
 The flat gradient buffer is cut into contiguous buckets that follow the order in which the backward pass
-finishes them (heads -> cross-attention -> encoder layers L-1..0 -> front-end), so each bucket's all-reduce
+finishes them (heads -> cross-attention -> encoder layers L-1..0 -> tokens -> conv-1 -> front-end), so each bucket's all-reduce
 is enqueued on a side stream as soon as its kernels are queued and overlaps the rest of the backward.
 The sum is turned into the mean by `grad_scale = 1/world_size` inside the clip/AdamW kernels.
 """
@@ -19,7 +19,16 @@ def bucket_ranges(names: List[str], offsets: Dict[str, int], total: int, num_lay
     """segment name (as emitted by Engine.backward) -> [begin, end) in floats of the flat buffer."""
     def first(prefix):
         return min(offsets[n] for n in names if n.startswith(prefix))
+    # front end, in registration order: cls_token, conv-0 | conv-1 (6.5 MB of the 7 MB) | token generators, extra heads, positions.
+    # Engine.backward releases "tokens" before the strided-conv backward starts and "conv1" right after conv-1's weight gradient
+    # -- ahead of its four backward-data phases and conv-0's gradient -- so only "frontend" (cls_token + conv-0, 0.2 MB) is left to
+    # reduce once backward has ended.
     marks = [("frontend", 0)]
+    c1 = [n for n in names if n.startswith("temporal_conv.convs.1.")]
+    if c1 and first("temporal_conv.convs.1.") > 0:
+        after = [offsets[n] for n in names if offsets[n] > max(offsets[m] for m in c1)]
+        if after and min(after) < first("encoder.layers.0."):
+            marks += [("conv1", first("temporal_conv.convs.1.")), ("tokens", min(after))]
     for l in range(num_layers):
         marks.append((f"layer{l}", first(f"encoder.layers.{l}.")))
     marks.append(("encoder.norm", first("encoder.norm.")))

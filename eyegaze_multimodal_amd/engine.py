@@ -1081,6 +1081,7 @@ class Engine:
         call("eg_batch_rowsum", ptr(dseq), fp.g_ptr("pos_embed.pos_embed.weight"), NB, S, d, S, self.dtype, st)
         call("eg_cast", fp.g_ptr("pos_embed.pos_embed.weight"), fp.g_ptr("cls_token"), d, EG_F32, st)
         self.model._extra_tokens_bwd(self, dseq)
+        seg("tokens")           # positions, token generators, the extra heads: everything registered between conv-1 and the encoder
         # conv1 backward: dY = dseq[:, off:, :] * relu/dropout gate
         ymap = rowmap(d, self.RY * d, self.T2)
         call("eg_rows_gather_gate", ptr(dseq), ptr(a["h1"]), ptr(g["dy1pad"]) + (self.J - 1) * d * es, ymap, NB, S, d,
@@ -1089,6 +1090,7 @@ class Engine:
         self.wgrad(dy1, ptr(a["h0pad"]), fp.g_ptr("temporal_conv.convs.1.weight"), NB * self.T2, d, self.k * d, y=ymap,
                    x=rowmap(self.s * d, self.R0 * d, self.T2), out_b=fp.g_ptr("temporal_conv.convs.1.bias"),
                    conv=(d, self.k, d))
+        seg("conv1")            # 6.5 MB of the front end's 7 MB: reduces under the backward-data phases and conv-0's gradient
         for ph in range(self.s):
             self.gemm(ptr(g["dy1pad"]), ptr(w["conv1T"]) + ph * d * self.J * d * es, ptr(g["dh0pad"]) + ph * d * es,
                       NB * self.U, d, self.J * d, a=rowmap(d, self.RY * d, self.U), c=rowmap(self.s * d, self.R0 * d, self.U),

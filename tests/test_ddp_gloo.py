@@ -18,7 +18,7 @@ from oracle import dual_eeg_oracle as O
 
 KW = dict(in_channels=8, max_len=256, num_classes=3, d_model=64, num_layers=2, num_heads=2, d_ff=128,
           use_spectrogram=False, use_ibs=False, use_cross_attention=True)
-SEGMENTS = ["heads", "cross", "encoder.norm", "layer1", "layer0", "frontend"]  # order Engine.backward emits
+SEGMENTS = ["heads", "cross", "encoder.norm", "layer1", "layer0", "tokens", "conv1", "frontend"]  # order Engine.backward emits
 
 
 def _free_port():
@@ -97,10 +97,16 @@ def test_bucket_order_matches_registration_order():
     fp = model._flat
     r = bucket_ranges(fp.names, fp.offsets, fp.total, 6, True)
     assert r["frontend"][0] == 0 and r["heads"][1] == fp.total
-    # every ibs / spectrogram / conv / pos parameter is in the front-end bucket, reduced last
+    # the front end is three buckets in registration order: cls_token + conv-0 (reduced last), conv-1, then every token generator /
+    # extra head / position parameter registered before the encoder
     for n in fp.names:
-        if n.startswith(("temporal_conv", "spectrogram", "ibs_", "pos_embed", "cls_token")):
+        if n.startswith(("temporal_conv.convs.0", "cls_token")):
             assert r["frontend"][0] <= fp.offsets[n] < r["frontend"][1], n
+        if n.startswith("temporal_conv.convs.1"):
+            assert r["conv1"][0] <= fp.offsets[n] < r["conv1"][1], n
+        if n.startswith(("spectrogram", "ibs_", "pos_embed")):
+            assert r["tokens"][0] <= fp.offsets[n] < r["tokens"][1], n
+    assert r["frontend"][1] == r["conv1"][0] and r["conv1"][1] == r["tokens"][0] and r["tokens"][1] == r["layer0"][0]
     assert r["layer5"][0] == fp.offsets["encoder.layers.5.mha.q_proj.weight"]
 
 

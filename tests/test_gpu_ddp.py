@@ -26,6 +26,6 @@ def test_two_rank_step_equals_global_batch_step(tmp_path):
     r1 = json.loads((tmp_path / "rank1.json").read_text())
     assert r0["same_params_as_rank0"] and r1["same_params_as_rank0"]
     assert r0["moved"] > 1e-4                                    # the optimiser really stepped
-    assert r0["segments"] == ["heads", "cross", "encoder.norm", "layer1", "layer0", "frontend"]
+    assert r0["segments"] == ["heads", "cross", "encoder.norm", "layer1", "layer0", "tokens", "conv1", "frontend"]
     assert r0["grad_rel_err"] < 2e-5, r0                         # mean of shard gradients == global-batch gradient (f32)
     assert r0["param_rel_err_after_2_steps"] < 2e-3, r0          # two clip + AdamW steps later the replicas match the single run

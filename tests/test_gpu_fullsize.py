@@ -159,7 +159,7 @@ def test_two_piece_weight_gradient_launch_is_bit_identical_and_releases_buckets_
     # (the cross-attention block's two weight gradients ride in the first piece of the grouped launch, so its bucket is released
     #  with the upper encoder layers', right after that piece -- still long before backward ends)
     head = ["heads", "encoder.norm", "cross"] if eng._wg_cross else ["heads", "cross", "encoder.norm"]   # (EYEGAZE_WGRAD_CROSS=0)
-    assert seen == head + [f"layer{l}" for l in reversed(range(L_))] + ["frontend"]
+    assert seen == head + [f"layer{l}" for l in reversed(range(L_))] + ["tokens", "conv1", "frontend"]
     assert calls_at[f"layer{L_ // 2 - 1}"] - calls_at["cross"] > 10
     # launches were issued between the release of layer L/2 and the release of layer L/2-1 (the lower half's backward)
     assert calls_at[f"layer{L_ // 2 - 1}"] - calls_at[f"layer{L_ // 2}"] > 10
