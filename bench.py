@@ -68,14 +68,40 @@ def plan_ranks(gpus: int, env: dict, share_gpu: bool = False, port: int = 0):
     return out
 
 
-def launch_ranks(plans) -> int:
-    """Starts one fresh interpreter per rank with this script's own arguments; rank 0's stdout is relayed verbatim."""
+def launch_ranks(plans, argv=None, timeout_s: float = None, poll_s: float = 0.2) -> int:
+    """Starts one fresh interpreter per rank with this script's own arguments; rank 0's stdout is relayed verbatim.
+    The children are POLLED: the first rank that exits non-zero (import error, GPU fault, failed rendezvous) ends the run -- its
+    siblings, which would otherwise sit in init_process_group / a collective until the collective timeout, are terminated (they
+    are this launcher's own fresh children, addressed by PID) and that status is returned.  A launcher-level timeout
+    (EYEGAZE_LAUNCH_TIMEOUT seconds, default 1500) bounds the whole run the same way."""
     import subprocess
-    procs = [subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=e,
+    argv = sys.argv[1:] if argv is None else argv
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("EYEGAZE_LAUNCH_TIMEOUT", "1500"))
+    procs = [subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=e,
                               stdout=(None if i == 0 else subprocess.DEVNULL)) for i, e in enumerate(plans)]
-    rc = 0
-    for p_ in procs:
-        rc = max(rc, abs(p_.wait()))
+    t0, rc, live = time.monotonic(), 0, list(procs)
+    while live and rc == 0:
+        for p_ in list(live):
+            st = p_.poll()
+            if st is not None:
+                live.remove(p_)
+                if st != 0:
+                    rc = abs(st) or 1
+        if live and rc == 0:
+            if time.monotonic() - t0 > timeout_s:
+                rc = 124
+                print(f"bench.py launcher: ranks still running after {timeout_s:.0f} s, terminating them", file=sys.stderr)
+                break
+            time.sleep(poll_s)
+    for p_ in live:                              # a failed or timed-out run: end what is left, by PID
+        p_.terminate()
+    for p_ in live:
+        try:
+            p_.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p_.kill()
+            p_.wait()
     return rc
 
 
@@ -163,8 +189,9 @@ def roofline_from_probes(probes, nsteps_probed, dtype):
             "dominant_by_bound": by_bound, "eg_gemm_nt_by_kernel": by_kernel}
 
 
-def run_mm5(args, dev):
-    """BASELINE configs[4] on one MI355X: the multimodal logit-fusion step of train_multimodal_fuzzy_fusion.py at B = 256."""
+def run_mm5(args, dev, world=1, rank=0, use_dist=False):
+    """BASELINE configs[4]: the multimodal logit-fusion step of train_multimodal_fuzzy_fusion.py at B = 256 per GPU; with more
+    than one rank the three gradient sets are exchanged by ddp.MultimodalReducers (weak scaling: every rank its own batch)."""
     import gc
     from eyegaze_multimodal_amd.train_multimodal_fuzzy_fusion import build_from_config, synth_multimodal
     B, C, T, F_, W_ = args.batch, 8, 1024, 64, 16
@@ -175,7 +202,8 @@ def run_mm5(args, dev):
                            "epochs": 10, "steps_per_epoch": 1000, "warmup_epochs": 1, "fp16": args.dtype == "fp16",
                            "compute_dtype": args.dtype}}
     tr = build_from_config(config, dev)
-    img1, img2, x1, x2, y = (t_.to(dev) for t_ in synth_multimodal(B, C, T, F_, W_, 3, seed=1234))
+    tr.force_dist = bool(args.force_dist)
+    img1, img2, x1, x2, y = (t_.to(dev) for t_ in synth_multimodal(B, C, T, F_, W_, 3, seed=1234 + rank))
     probes = []
     tr.train_step(img1, img2, x1, x2, y)                      # lazy workspaces, one-time kernel attributes
     engines = tr._engines(B, T, F_, W_)
@@ -195,6 +223,8 @@ def run_mm5(args, dev):
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         tr.train_step(img1, img2, x1, x2, y)
+    if use_dist:
+        dist.barrier()
     torch.cuda.synchronize()
     gc.collect()
     gc.disable()
@@ -203,24 +233,34 @@ def run_mm5(args, dev):
         for e in engines:
             e.probe_all = probes if i < n_probe_steps else None
         out = tr.train_step(img1, img2, x1, x2, y)
+    if use_dist:
+        dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    if use_dist:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
     loss = float(out["loss"])
     assert loss == loss, "loss is NaN"
     eeg = engines[0]
-    res = {"metric": "train samples/sec (gaze+EEG windows)", "value": round(B * args.steps / elapsed, 2), "unit": "samples/s",
-           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-           "config": {"workload": f"mm5: {WORKLOADS['mm5'][1]}", "batch_per_gpu": B, "global_batch": B, "C": C, "T": T,
-                      "image": [F_, W_], "seq_len": eeg.S, "d_model": 256, "layers": 6,
-                      "step": "fwd(image CNN + EEG, train, dropout) + fuzzy fusion + losses + bwd + global clip + per-group AdamW"
-                              + (" + loss scaling" if args.dtype == "fp16" else ""),
-                      "parallelism": "dp1", "final_loss": round(loss, 5)},
-           "roofline": roofline_from_probes(probes, n_probe_steps, args.dtype)}
-    if not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline_mm5(tr, C, T, F_, W_, Bc=args.cpu_batch)
-    print(json.dumps(res), flush=True)
+    if rank == 0:
+        res = {"metric": "train samples/sec (gaze+EEG windows)", "value": round(world * B * args.steps / elapsed, 2), "unit": "samples/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": f"mm5: {WORKLOADS['mm5'][1]}", "batch_per_gpu": B, "global_batch": world * B, "C": C, "T": T,
+                          "image": [F_, W_], "seq_len": eeg.S, "d_model": 256, "layers": 6,
+                          "step": "fwd(image CNN + EEG, train, dropout) + fuzzy fusion + losses + bwd"
+                                  + (" + 3-set gradient all-reduce" if use_dist else "") + " + global clip + per-group AdamW"
+                                  + (" + loss scaling" if args.dtype == "fp16" else ""),
+                          "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
+               "roofline": roofline_from_probes(probes, n_probe_steps, args.dtype)}
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline_mm5(tr, C, T, F_, W_, Bc=args.cpu_batch)
+        print(json.dumps(res), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
 
 
 def cpu_baseline_mm5(tr, C, T, F_, W_, Bc=256, seconds_budget=30.0):
@@ -323,9 +363,7 @@ def main():
     from eyegaze_multimodal_amd.ddp import GradAllReducer, broadcast_params, bucket_ranges
 
     if args.workload == "mm5":
-        if world > 1:
-            raise SystemExit("--workload mm5 is a single-GPU measurement (the multimodal loop has no gradient reducer)")
-        return run_mm5(args, dev)
+        return run_mm5(args, dev, world, rank, use_dist)
     T, B = 1024, args.batch
     kw, desc = WORKLOADS[args.workload]
     kw = dict(kw, num_classes=3)

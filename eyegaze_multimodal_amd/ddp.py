@@ -43,12 +43,14 @@ def bucket_ranges(names: List[str], offsets: Dict[str, int], total: int, num_lay
 
 
 class GradAllReducer:
-    def __init__(self, flat_grad: torch.Tensor, ranges: Dict[str, Tuple[int, int]], group=None, force: bool = False):
+    def __init__(self, flat_grad: torch.Tensor, ranges: Dict[str, Tuple[int, int]], group=None, force: bool = False,
+                 comm_stream=None):
+        """comm_stream: share one side stream between the reducers of several flat buffers (the multimodal model has three)."""
         self.g, self.ranges, self.group = flat_grad, ranges, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = force and dist.is_initialized()   # exercise the collective path even with one rank (rehearsal)
         self.cuda = flat_grad.is_cuda
-        self.comm_stream = torch.cuda.Stream(flat_grad.device) if self.cuda else None
+        self.comm_stream = (comm_stream or torch.cuda.Stream(flat_grad.device)) if self.cuda else None
         self.works = []
 
     def on_segment(self, name: str):
@@ -79,6 +81,62 @@ class GradAllReducer:
     @property
     def grad_scale(self) -> float:
         return 1.0 / self.world
+
+
+class MultimodalReducers:
+    """The gradient exchange of the three-parameter-set multimodal model (train_multimodal_fuzzy_fusion.py: gaze encoder, EEG
+    encoder, fusion scalars -- one optimizer over three param groups in the reference, :727-737): one GradAllReducer per flat
+    gradient buffer on ONE shared side stream, released in the order the step finishes them -- fusion scalars (ready after the
+    [B, K] autograd graph), the image branch (ready after its short backward, reduces under the EEG backward), then the EEG
+    encoder's buckets as Engine.backward emits them.  `sync_flag` makes the fp16 overflow decision collective: every rank's
+    eg_clip_coef sees the same reduced gradients, so the flags already agree by construction; the MAX all-reduce of the one
+    found_inf word keeps the replicas in lock-step even if a backend ever returned rank-dependent roundings."""
+
+    def __init__(self, eeg_fp, gaze_fp, fus_fp, num_layers: int, use_cross: bool, group=None, force: bool = False):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized() and (self.world > 1 or force)
+        whole = lambda fp: {"all": (0, fp.total)}
+        self.eeg = self.gaze = self.fusion = None
+        stream = None
+        if eeg_fp is not None and eeg_fp.grad is not None:
+            self.eeg = GradAllReducer(eeg_fp.grad, bucket_ranges(eeg_fp.names, eeg_fp.offsets, eeg_fp.total, num_layers, use_cross),
+                                      group, force)
+            stream = self.eeg.comm_stream
+        if gaze_fp is not None and gaze_fp.grad is not None:
+            self.gaze = GradAllReducer(gaze_fp.grad, whole(gaze_fp), group, force, comm_stream=stream)
+            stream = stream or self.gaze.comm_stream
+        self.fusion = GradAllReducer(fus_fp.grad, whole(fus_fp), group, force, comm_stream=stream)
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def on_fusion(self):
+        self.fusion.on_segment("all")
+
+    def on_gaze(self):
+        if self.gaze is not None:
+            self.gaze.on_segment("all")
+
+    @property
+    def on_eeg_segment(self):
+        return self.eeg.on_segment if (self.eeg is not None and self.active) else None
+
+    def finish(self):
+        for r in (self.fusion, self.gaze, self.eeg):
+            if r is not None:
+                r.finish()
+
+    def sync_flag(self, state_dev: torch.Tensor):
+        """MAX over ranks of eg_step_state.found_inf (word 9), stream-ordered between eg_clip_coef and the AdamW kernels."""
+        if self.active:
+            dist.all_reduce(state_dev[9:10], op=dist.ReduceOp.MAX, group=self.group)
+
+    def broadcast(self, *flats):
+        for f in flats:
+            if f is not None:
+                broadcast_params(f, self.group)
 
 
 def broadcast_params(flat: torch.Tensor, group=None):

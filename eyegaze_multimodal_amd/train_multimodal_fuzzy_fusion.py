@@ -16,6 +16,12 @@ fp16 (config training.fp16, :752-753): dynamic loss scaling with GradScaler's se
 gradient is multiplied by the device-resident scale, eg_clip_coef un-scales and flags non-finite norms, every AdamW kernel skips
 on the flag, eg_scaler_update backs off / grows.  The three parameter sets share ONE eg_step_state (one scale, one flag, one
 clip coefficient), exactly as one GradScaler + one clip_grad_norm_(model.parameters()) do in the reference.
+
+Data parallel (BASELINE configs[4] is an 8-GPU configuration; the reference itself is single-process): one process per GPU,
+rank r trains on samples r::world of the global batch; the three flat gradient buffers are summed over ranks by
+ddp.MultimodalReducers on one side stream (fusion scalars first, the image branch under the EEG backward, the EEG encoder's
+buckets as its backward releases them), 1/world is folded into eg_clip_coef / eg_adamw_group, and the overflow flag is made
+collective before any AdamW kernel reads it, so an fp16 overflow on ONE rank skips the step on EVERY rank.
 """
 from __future__ import annotations
 
@@ -61,8 +67,12 @@ class MultimodalTrainer:
     def __init__(self, model: MultimodalFusionModel, device, *, encoder_lr: float = 1e-4, fusion_lr: float = 1e-3,
                  weight_decay: float = 0.01, max_grad_norm: Optional[float] = 1.0, lambda_aux_img: float = 0.3,
                  lambda_aux_eeg: float = 0.3, lambda_reg: float = 0.1, temp_reg_min: float = 0.5, temp_reg_max: float = 5.0,
-                 warmup_steps: int = 0, total_steps: int = 1, betas=(0.9, 0.999), eps: float = 1e-8, seed: int = 0):
+                 warmup_steps: int = 0, total_steps: int = 1, betas=(0.9, 0.999), eps: float = 1e-8, seed: int = 0,
+                 group=None, force_dist: bool = False):
+        """group / force_dist: data-parallel exchange over torch.distributed (active when a process group is initialised and has
+        more than one rank; force_dist runs the collective path with a single rank as a rehearsal)."""
         self.model, self.device = model.to(device), torch.device(device)
+        self.group, self.force_dist, self.red = group, force_dist, None
         self.encoder_lr, self.fusion_lr, self.wd, self.max_norm = encoder_lr, fusion_lr, weight_decay, max_grad_norm
         self.lams = (lambda_aux_img, lambda_aux_eeg, lambda_reg)
         self.treg = (temp_reg_min, temp_reg_max)
@@ -84,6 +94,19 @@ class MultimodalTrainer:
         img.scaler_on = eeg.scaler_on          # one scale / one overflow flag for the whole model
         return eeg, img
 
+    def _reducers(self, eeg, img):
+        """The data-parallel exchange, built on first use (None in a single-process run): parameters of all three sets are
+        broadcast from rank 0 once, so the replicas start identical whatever each rank's initialisation was."""
+        import torch.distributed as dist
+        if self.red is None and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force_dist):
+            from .ddp import MultimodalReducers
+            m = self.model
+            ecfg = m.eeg_encoder.cfg
+            self.red = MultimodalReducers(None if m.freeze_eeg else eeg.fp, None if m.freeze_gaze else img.fp, self.fus,
+                                          ecfg.num_layers, ecfg.use_cross_attention, self.group, self.force_dist)
+            self.red.broadcast(eeg.fp.flat, img.fp.flat, self.fus.flat)
+        return self.red
+
     def _moments(self, name, fp):
         if name not in self.state:
             self.state[name] = (torch.zeros_like(fp.flat), torch.zeros_like(fp.flat))
@@ -99,9 +122,11 @@ class MultimodalTrainer:
         B, _, T = eeg1.shape
         F_, W_ = img1.shape[-2], img1.shape[-1]
         eeg, img = self._engines(B, T, F_, W_)
+        red = self._reducers(eeg, img)
         lr = self.encoder_lr * self.current_lr_factor()           # scheduler.step() follows optimizer.step(): step k uses lambda(k)
         t = self.step_no + 1
-        eeg.set_state(seed=self.seed * 7919 + t, lr=lr, step=t, beta1=self.betas[0], beta2=self.betas[1])
+        eeg.set_state(seed=self.seed * 7919 + t, lr=lr, step=t, beta1=self.betas[0], beta2=self.betas[1],
+                      grad_scale=(red.grad_scale if red else 1.0))
         # ---- forward of both encoders (HIP) ----
         z_img = img.forward(img1.contiguous().float(), img2.contiguous().float(), train=dropout).detach().clone().requires_grad_(True)
         eeg.forward(eeg1.contiguous().float(), eeg2.contiguous().float(), labels, train=dropout)
@@ -119,16 +144,22 @@ class MultimodalTrainer:
         loss = loss_ce + li * loss_aux_img + le * loss_aux_eeg + lr_ * loss_reg
         scale = eeg.loss_scale_dev if eeg.scaler_on else None     # scaler.scale(loss).backward() (:462)
         (loss * scale if scale is not None else loss).sum().backward()
-        # ---- encoders' backwards from the (scaled) logit gradients ----
-        if not m.freeze_gaze:
-            img.backward(z_img.grad)
-        if not m.freeze_eeg:
-            eeg.backward(glogits=z_eeg.grad, prescaled=True)
         fus = self.fus
         for n, p in zip(fus.names, fus.params):
             o = fus.offsets[n]
             g = p.grad if p.grad is not None else torch.zeros_like(p)
             fus.grad[o:o + p.numel()].copy_(g.reshape(-1))
+        if red:
+            red.on_fusion()
+        # ---- encoders' backwards from the (scaled) logit gradients ----
+        if not m.freeze_gaze:
+            img.backward(z_img.grad)
+            if red:
+                red.on_gaze()                 # the image branch's gradients travel under the EEG encoder's backward
+        if not m.freeze_eeg:
+            eeg.backward(glogits=z_eeg.grad, prescaled=True, on_segment=(red.on_eeg_segment if red else None))
+        if red:
+            red.finish()
         # ---- scaler.unscale_ + clip_grad_norm_(model.parameters()) + scaler.step + scaler.update (:464-472) ----
         self._optimizer_step(eeg, img)
         self.step_no += 1
@@ -151,6 +182,8 @@ class MultimodalTrainer:
         for i, (_, fp, _) in enumerate(sets):
             call("eg_grad_sqnorm", ptr(fp.grad), fp.total, ptr(self.sqpart) + 4 * i * nblk, nblk, st)
         call("eg_clip_coef", ptr(self.sqpart), 3 * nblk, float(self.max_norm or 0.0), eeg.st_ptr, st)
+        if self.red:
+            self.red.sync_flag(eeg.state_dev)
         for name, fp, mult in sets:
             mm, vv = self._moments(name, fp)
             call("eg_adamw_group", ptr(fp.flat), ptr(fp.grad), ptr(mm), ptr(vv), fp.total, self.betas[0], self.betas[1], self.eps,

@@ -45,3 +45,58 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["workload"] == "cfg3"
+
+
+def test_gpus_2_multimodal_workload_spawns_two_ranks():
+    """BASELINE configs[4] is a multi-GPU configuration: --workload mm5 must accept N > 1 (it used to exit)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--workload", "mm5", "--backend", "gloo",
+                        "--share-gpu", "--plan-only"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["workload"] == "mm5"
+    assert "single-GPU measurement" not in (REPO / "bench.py").read_text()
+
+
+def test_launcher_ends_the_run_when_one_rank_dies(tmp_path):
+    """one rank exits non-zero at once, its sibling would sleep for minutes: the launcher must return that status promptly
+    and leave no child behind"""
+    import time
+    b = _bench()
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "open(os.environ['PIDFILE'] + os.environ['RANK'], 'w').write(str(os.getpid()))\n"
+                      "sys.exit(7) if os.environ['RANK'] == '1' else time.sleep(600)\n")
+    plans = [dict(os.environ, RANK=str(r), PIDFILE=str(tmp_path / "pid")) for r in range(2)]
+    real = b.Path
+    try:
+        b.Path = lambda *_a, **_k: real(script)          # the launcher starts `python <this file>`: point it at the stub rank
+        t0 = time.monotonic()
+        rc = b.launch_ranks(plans, argv=[], timeout_s=120)
+    finally:
+        b.Path = real
+    assert rc == 7 and time.monotonic() - t0 < 60
+    pid0 = int((tmp_path / "pid0").read_text())
+    time.sleep(0.2)
+    alive = True
+    try:
+        os.kill(pid0, 0)
+        alive = Path(f"/proc/{pid0}/stat").read_text().split()[2] != "Z"
+    except (ProcessLookupError, FileNotFoundError):
+        alive = False
+    assert not alive
+
+
+def test_launcher_timeout(tmp_path):
+    import time
+    b = _bench()
+    script = tmp_path / "rank.py"
+    script.write_text("import time\ntime.sleep(600)\n")
+    real = b.Path
+    try:
+        b.Path = lambda *_a, **_k: real(script)
+        t0 = time.monotonic()
+        rc = b.launch_ranks([dict(os.environ), dict(os.environ)], argv=[], timeout_s=2)
+    finally:
+        b.Path = real
+    assert rc == 124 and time.monotonic() - t0 < 40
