@@ -258,7 +258,7 @@ def run_mm5(args, dev, world=1, rank=0, use_dist=False):
                "roofline": roofline_from_probes(probes, n_probe_steps, args.dtype)}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline_mm5(tr, C, T, F_, W_, Bc=args.cpu_batch)
-        print(json.dumps(res), flush=True)
+        emit(res)
     if use_dist:
         dist.destroy_process_group()
 
@@ -293,6 +293,28 @@ def cpu_baseline_mm5(tr, C, T, F_, W_, Bc=256, seconds_budget=30.0):
                       f"{n} timed steps after 1 warm-up"}
 
 
+_REAL_STDOUT = None
+
+
+def protect_stdout():
+    """The contract is ONE JSON line on stdout, but libraries write to file descriptor 1 on their own (RCCL prints a version
+    banner at communicator creation, gloo a connection note).  Everything this process and its libraries print goes to stderr
+    from here on; `emit` writes the result line to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+        sys.stdout = os.fdopen(os.dup(2), "w")
+
+
+def emit(obj):
+    line = json.dumps(obj)
+    out = _REAL_STDOUT or sys.stdout
+    out.write(line + "\n")
+    out.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,6 +344,7 @@ def main():
     plans = plan_ranks(args.gpus, os.environ, share_gpu=args.share_gpu)
     if plans:                                  # launcher: nothing below runs in this process, the GPU stays untouched
         sys.exit(launch_ranks(plans))
+    protect_stdout()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -340,7 +363,7 @@ def main():
             assert int(tot) == world
             dist.barrier()
         if rank == 0:
-            print(json.dumps({"plan_only": True, "n_gpus": world, "workload": args.workload, "local_rank": local_rank}), flush=True)
+            emit({"plan_only": True, "n_gpus": world, "workload": args.workload, "local_rank": local_rank})
         if use_dist:
             dist.destroy_process_group()
         return
@@ -521,7 +544,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(kw, C, T, Bc=args.cpu_batch)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dist:
         dist.destroy_process_group()
 

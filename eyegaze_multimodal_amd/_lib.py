@@ -13,7 +13,7 @@ LIB_PATH = _PKG / "libeyegaze_hip.so"
 
 EG_F32, EG_BF16, EG_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class EgError(RuntimeError):
@@ -110,7 +110,7 @@ SIGNATURES = {
     "eg_unpack_conv_wgrad": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "eg_colsum": [_P, RowMap, _I, _I, _P, _I, _I, _P],
     "eg_layernorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "eg_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U, _F, _U, _P, _P],
+    "eg_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _F, _U, _P, _P],
     "eg_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _P, _P],
     "eg_attention_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U, _P, _P],
     "eg_window_normalize": [_P, _P, _P, _I, _I, _I, _I, _P],

@@ -290,11 +290,15 @@ extern "C" int eg_layernorm_fwd(const void* x, const float* gamma, const float* 
 }
 
 extern "C" int eg_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
-                                void* dx_drop, float* partial, int nblk, int M, int D, int dtype, float drop1_p,
-                                uint32_t drop1_site, float drop2_p, uint32_t drop2_site, const eg_step_state* state,
-                                void* stream) {
+                                void* dx_drop, float* partial, int nblk, int partial_capacity_blocks, int M, int D, int dtype,
+                                float drop1_p, uint32_t drop1_site, float drop2_p, uint32_t drop2_site,
+                                const eg_step_state* state, void* stream) {
   EG_CHECK(dy && x && stats && gamma && dx && partial, "eg_layernorm_bwd: null pointer");
   EG_CHECK(M > 0 && D > 0 && D % 4 == 0 && D <= 1024 && nblk > 0, "eg_layernorm_bwd: bad shape");
+  // every workgroup writes its own [2, D] row of `partial`: a grid larger than the buffer is an out-of-bounds store (round 2: a
+  // 2080-block sweep into a 2048-block buffer ended in a GPU memory access fault), so the caller states the capacity
+  EG_CHECK(nblk <= partial_capacity_blocks, "eg_layernorm_bwd: nblk %d exceeds the partial buffer's capacity of %d blocks",
+           nblk, partial_capacity_blocks);
   EG_CHECK((drop1_p == 0.f && drop2_p == 0.f) || state, "eg_layernorm_bwd: dropout needs a step state");
   EG_CHECK((long long)M * D < (1ll << 32), "eg_layernorm_bwd: M*D exceeds the 32-bit dropout index");
   DropCfg d1 = make_drop(drop1_p, drop1_site), d2 = make_drop(drop2_p, drop2_site);

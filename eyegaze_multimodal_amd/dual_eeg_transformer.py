@@ -240,6 +240,8 @@ class DualEEGTransformer(nn.Module):
         self._dtype = _resolve_dtype(compute_dtype)
         self._flat = FlatParams(self)
         self._engines: Dict[tuple, Engine] = {}
+        self._step_states: Dict[str, torch.Tensor] = {}
+        self._state_ready: Dict[str, bool] = {}
         self._fwd_count = 0
         self._seed_base = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
         from . import ops
@@ -249,15 +251,34 @@ class DualEEGTransformer(nn.Module):
     def engine(self, B: int, T: int, device: torch.device) -> Engine:
         L.lib()  # raises when the HIP library is missing
         device = torch.device(device)
+        if device.type == "cuda" and device.index is None:      # "cuda" and "cuda:0" must name ONE engine and ONE step state
+            device = torch.device("cuda", torch.cuda.current_device())
         self._flat.ensure(device)
         key = (B, T, str(device), self._dtype)
         eng = self._engines.get(key)
         if eng is None:
             if len(self._engines) >= 4:  # bound the workspace held for rarely used shapes
                 self._engines.pop(next(iter(self._engines)))
-            eng = Engine(self, B, T, device, self._dtype)
+            eng = Engine(self, B, T, device, self._dtype, state_dev=self._state_for(device))
+            if not self._state_ready.get(str(device)):
+                # first engine on this device: it owns the initialisation of the shared step state (loss scaling on for fp16)
+                eng.set_state(seed=0, lr=0.0, step=1, grad_scale=1.0, reset_scaler=(1 if eng.scaler_on else 2),
+                              init_scale=eng.scaler_cfg["init_scale"])
+                self._state_ready[str(device)] = True
             self._engines[key] = eng
         return eng
+
+    def _state_for(self, device: torch.device) -> torch.Tensor:
+        """ONE eg_step_state per (model, device), shared by the engines of every batch shape: the tail batch of an epoch steps
+        the same AdamW count (bias corrections under fp16 come from the device's own opt_steps), the same loss scale and the
+        same overflow history as the full batches (round-2 ADVICE: each engine used to carry a private state)."""
+        key = str(device)
+        st = self._step_states.get(key)
+        if st is None:
+            st = torch.zeros(L.STATE_WORDS, dtype=torch.int32, device=device)
+            self._step_states[key] = st
+            self._state_ready[key] = False
+        return st
 
     def _run_forward(self, eng: Engine, eeg1, eeg2, labels, train: Optional[bool] = None) -> Dict[str, torch.Tensor]:
         train = self.training if train is None else train
@@ -290,7 +311,16 @@ class DualEEGTransformer(nn.Module):
         from . import tokens
         tokens.fire_spec_backward_hooks(self, eng)
         fp = self._flat
-        flat = fp.grad.clone()
+        if eng.scaler_on:
+            # fp16: the HIP backward carried every gradient at loss_scale x its value (so fp16 intermediates stay representable).
+            # That scale is internal to the engine: what autograd hands to p.grad is the TRUE gradient, so the reference's own
+            # loop (loss.backward(); clip_grad_norm_; torch AdamW, train_art.py:178-222) -- or an outer GradScaler -- sees
+            # ordinary magnitudes; non-finite entries stay non-finite (inf / scale = inf) and are visible to the caller, and
+            # the internal scale backs off / grows exactly as in the native step (eg_clip_coef flags, eg_scaler_update adapts).
+            flat = fp.grad / eng.loss_scale_dev
+            eng.check_overflow_and_update_scaler()
+        else:
+            flat = fp.grad.clone()
         return [flat[fp.offsets[n]:fp.offsets[n] + p.numel()].view(p.shape) for n, p in zip(fp.names, fp.params)]
 
     def forward(self, eeg1: torch.Tensor, eeg2: torch.Tensor, labels: Optional[torch.Tensor] = None) -> dict:

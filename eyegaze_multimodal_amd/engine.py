@@ -104,9 +104,14 @@ class FlatParams:
 
 class Engine:
     """Workspace + kernel sequencing for a fixed (B, T) shape."""
+    LN_PARTIAL_BLOCKS = 2048      # rows of [2, d] the LayerNorm-backward scratch partial buffer holds (g["lnpart"])
 
-    def __init__(self, model, B: int, T: int, device: torch.device, dtype: int):
+    def __init__(self, model, B: int, T: int, device: torch.device, dtype: int, state_dev: Optional[torch.Tensor] = None):
+        """state_dev: the model's shared eg_step_state.  Every engine of one model (one per batch shape: the ragged tail batch
+        of an epoch gets its own workspace) must step ONE optimiser count, ONE loss scale and ONE overflow history; an engine
+        given no state creates (and initialises) its own."""
         cfg = model.cfg
+        self._shared_state = state_dev
         self.model, self.cfg, self.B, self.T, self.device, self.dtype = model, cfg, B, T, device, dtype
         self.tdtype = {EG_BF16: torch.bfloat16, EG_F16: torch.float16, EG_F32: torch.float32}[dtype]
         self.es = 4 if dtype == EG_F32 else 2
@@ -165,7 +170,11 @@ class Engine:
         # evenly -- 33 280 rows: 1040 blocks x 4 trips, against 512 blocks x 8.1 -> 9 trips (measured 3.90 -> 3.87 ms / step)
         env_nb = os.environ.get("EYEGAZE_LN_BLOCKS")
         trips = max(1, self.M // 8192)
-        self.LN_BLOCKS = min(2048, int(env_nb) if env_nb else max(1, (self.M + 8 * trips - 1) // (8 * trips)))
+        self.LN_BLOCKS = int(env_nb) if env_nb else min(self.LN_PARTIAL_BLOCKS, max(1, (self.M + 8 * trips - 1) // (8 * trips)))
+        if not 1 <= self.LN_BLOCKS <= self.LN_PARTIAL_BLOCKS:
+            # round 2: a sweep at 2080 blocks stored past the 2048-row partial buffer (GPU memory access fault); refuse, never clamp
+            raise L.EgError(f"EYEGAZE_LN_BLOCKS={env_nb} is outside [1, {self.LN_PARTIAL_BLOCKS}] (rows of the LayerNorm-backward "
+                            "partial buffer)")
         self.ln_nblk_cap = max(self.LN_BLOCKS, (self.M + 63) // 64)
         if (self.M + 63) // 64 > 2048:
             self.fuse_ln = False      # the scratch partial buffer holds 2048 workgroups
@@ -266,9 +275,12 @@ class Engine:
         # backward temporaries (allocated lazily on the first backward)
         self.g: Dict[str, torch.Tensor] = {}
         # device-resident step state (eg_step_state); the host publishes a step's scalars as kernel arguments
-        self.state_dev = torch.zeros(L.STATE_WORDS, dtype=torch.int32, device=self.device)
-        self.set_state(seed=0, lr=0.0, step=1, grad_scale=1.0, reset_scaler=(1 if self.scaler_on else 2),
-                       init_scale=self.scaler_cfg["init_scale"])
+        if self._shared_state is not None:      # initialised once, by whoever created it (DualEEGTransformer._state_for)
+            self.state_dev = self._shared_state
+        else:
+            self.state_dev = torch.zeros(L.STATE_WORDS, dtype=torch.int32, device=self.device)
+            self.set_state(seed=0, lr=0.0, step=1, grad_scale=1.0, reset_scaler=(1 if self.scaler_on else 2),
+                           init_scale=self.scaler_cfg["init_scale"])
 
     def _alloc_bwd(self):
         if self.g:
@@ -294,7 +306,7 @@ class Engine:
         # TN split-K partials: sized for the largest product (conv-1 weights / FFN)
         self.tn_cap = 24 * 1024 * 1024  # floats (96 MB)
         g["partial"] = self._t(self.tn_cap, dtype=torch.float32)
-        g["lnpart"] = self._t(2048 * 2 * max(d, 8), dtype=torch.float32)
+        g["lnpart"] = self._t(self.LN_PARTIAL_BLOCKS * 2 * max(d, 8), dtype=torch.float32)
         g["cspart"] = self._t(512 * max(3 * d, F), dtype=torch.float32)
         self.g = g
 
@@ -317,6 +329,19 @@ class Engine:
         self.scaler_cfg = dict(init_scale=init_scale, growth=growth, backoff=backoff, growth_interval=growth_interval)
         self.scaler_on = True
         self.set_state(seed=0, lr=0.0, step=1, reset_scaler=1, init_scale=init_scale)
+
+    def check_overflow_and_update_scaler(self):
+        """autograd path at fp16: flags a non-finite gradient norm (eg_step_state.found_inf) and adapts the internal loss scale,
+        as the native optimiser step does between eg_clip_coef and eg_scaler_update -- without touching parameters."""
+        self._alloc_bwd()
+        self.stream = self._cur_stream()
+        nblk = 1024
+        if "sqpart" not in self.g:
+            self.g["sqpart"] = self._t(nblk, dtype=torch.float32)
+        call("eg_grad_sqnorm", ptr(self.fp.grad), self.fp.total, ptr(self.g["sqpart"]), nblk, self.stream)
+        call("eg_clip_coef", ptr(self.g["sqpart"]), nblk, 0.0, self.st_ptr, self.stream)
+        c = self.scaler_cfg
+        call("eg_scaler_update", self.st_ptr, c["growth"], c["backoff"], c["growth_interval"], self.stream)
 
     @property
     def loss_scale_dev(self) -> torch.Tensor:
@@ -604,8 +629,9 @@ class Engine:
         def tables(layers, with_cross=False, nsplit=None):
             """TN problem table + reduce table (weights, biases and the deferred LayerNorm gain / bias partials) of `layers`
             (+ the cross-attention block's two products); block ranges are relative to the tables' own launches.  Which launch
-            a product rides in changes neither its split nor its summation order, so every piece arrangement yields bit-identical
-            gradients."""
+            a product rides in does not change its result AT EQUAL nsplit (same row split, same ordered sum); the data-parallel
+            pieces run with more row splits than the single launch (splits_p vs splits), so their gradients differ from the
+            single launch's by fp32 summation order (~2e-6 relative), each arrangement deterministic in itself."""
             nsplit = nsplit or splits
             sel = [4 * l + j for l in layers for j in range(4)]
             if with_cross:
@@ -708,8 +734,9 @@ class Engine:
         d = self.cfg.d_model
         nblk = self.LN_BLOCKS
         lp = ptr(self.g["lnpart"]) if slot is None else ptr(self.g["lnpart_all"]) + 4 * slot * self.ln_nblk_cap * 2 * d
+        cap = self.LN_PARTIAL_BLOCKS if slot is None else self.ln_nblk_cap      # rows of [2, d] behind `lp`
         call("eg_layernorm_bwd", ptr(dy), ptr(x), ptr(stats), self.fp.p_ptr(gname + ".weight"), ptr(dx), ptr(dx_drop),
-             lp, nblk, self.M, d, self.dtype, d1[0], d1[1], d2[0], d2[1], self.st_ptr, self.stream)
+             lp, nblk, cap, self.M, d, self.dtype, d1[0], d1[1], d2[0], d2[1], self.st_ptr, self.stream)
         if slot is not None:
             return
         if self.fp.offsets[gname + ".bias"] == self.fp.offsets[gname + ".weight"] + d:   # (gain | bias) back to back

@@ -47,6 +47,8 @@ class GazeCNNEncoder(nn.Module):
     def engine(self, B: int, F: int, W: int, device, state_dev: Optional[torch.Tensor] = None) -> "ImageEngine":
         L.lib()
         device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         self._flat.ensure(device)
         key = (B, F, W, str(device), self._dtype)
         if key not in self._engines:
@@ -70,6 +72,8 @@ class ImageEngine(Engine):
         self.bk = 32 if dtype == EG_F32 else 64
         self.fp = model._flat
         self.stream, self.probes, self.probe_all = 0, {}, None
+        self.cus = torch.cuda.get_device_properties(device).multi_processor_count if torch.device(device).type == "cuda" else 256
+        self._shared_state = state_dev
         self._recording, self._plan = False, []
         self.scaler_on = False
         self.scaler_cfg = dict(init_scale=65536.0, growth=2.0, backoff=0.5, growth_interval=2000)

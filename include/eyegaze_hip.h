@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define EG_ABI_VERSION 3
+#define EG_ABI_VERSION 4
 enum { EG_F32 = 0, EG_BF16 = 1, EG_F16 = 2 };
 enum { EG_ACT_NONE = 0, EG_ACT_RELU = 1, EG_ACT_GELU = 2 };
 
@@ -273,15 +273,16 @@ int eg_colsum(const void* Y, eg_rowmap y, int M, int N, float* partial, int nblk
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm(eps=1e-5) over the last dim  — A:283,286,293,295,306,328; D:952,968,972
  *   fwd: y = (x-mean)*rstd*gamma+beta, stats [M,2] = (mean, rstd)
- *   bwd: dx from dy; per-block partial dgamma/dbeta [nblk, 2, D] (sum with eg_reduce_partials);
+ *   bwd: dx from dy; per-block partial dgamma/dbeta [nblk, 2, D] (sum with eg_reduce_partials); `partial` holds
+ *        partial_capacity_blocks such rows and nblk beyond that is rejected on the host before any launch;
  *        optional dx_drop = dropout-masked dx (the gradient entering the branch whose output was dropped
  *        before the residual add: drop1/drop2 of A:293,295 and the FeedForward's own final dropout A:272)
  * ------------------------------------------------------------------------------------------- */
 int eg_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int M, int D,
                      int dtype, void* stream);
 int eg_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, void* dx_drop,
-                     float* partial, int nblk, int M, int D, int dtype, float drop1_p, uint32_t drop1_site,
-                     float drop2_p, uint32_t drop2_site, const eg_step_state* state, void* stream);
+                     float* partial, int nblk, int partial_capacity_blocks, int M, int D, int dtype, float drop1_p,
+                     uint32_t drop1_site, float drop2_p, uint32_t drop2_site, const eg_step_state* state, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-head attention core on a fused [NB*S, 3*D] q|k|v buffer — A:206-212; cross form D:967,971

@@ -102,6 +102,16 @@ SCALAR_BANDS: List[Tuple[float, float]] = [(4, 8), (8, 13), (13, 30), (30, 45)]
 DROPOUT_OVERRIDE = None
 CTX = {"stream": 0}
 SPEC_CONV2_TAPS = None   # tests may set this to a list: spectrogram_tokens appends its second conv's output (pre-ReLU)
+# Storage-format model.  The HIP path keeps activations in its compute dtype (bf16 / fp16) between kernels and accumulates in
+# fp32 inside them.  STORAGE_ROUND(t, site), when installed, is applied at exactly the points where the HIP path writes an
+# activation to HBM (xt, h0pad, x0, q|k|v, attention probabilities as the PV operand, ctx, r1, y1, hff, r2, x_l,
+# zn, the cross block's rx / zc, comb, zf, hcl; the token generators' stored stages), so that `fp32 arithmetic + bf16 storage`
+# can be measured against the fp32 reference: tests/bf16_floor.py.  None (default) = the reference's fp32 everywhere.
+STORAGE_ROUND = None
+
+
+def _st(t: Tensor, site: str) -> Tensor:
+    return t if STORAGE_ROUND is None else STORAGE_ROUND(t, site)
 
 
 def _dropout(t: Tensor, p: float, site) -> Tensor:
@@ -115,13 +125,15 @@ def _dropout(t: Tensor, p: float, site) -> Tensor:
 def temporal_conv(x: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, p_drop: float = 0.0) -> Tensor:
     """[B,C,T] -> [B,T~,d]: (conv1d k,stride,pad=k//2 -> ReLU -> dropout(0.1 in train)) x L, then
     channel-last.  D:170-174.  p_drop=0 restates eval mode."""
-    h = x
+    h = _st(x, "xt")
     for i in range(cfg.conv_layers):
         w = sd[f"temporal_conv.convs.{i}.weight"]
         b = sd[f"temporal_conv.convs.{i}.bias"]
         h = F.conv1d(h, w, b, stride=cfg.conv_stride, padding=cfg.conv_kernel_size // 2)
         h = torch.relu(h)
         h = _dropout(h, p_drop, ("conv", i))
+        if i + 1 < cfg.conv_layers:          # (the last layer's rows are stored once, with the positional rows added: "x0")
+            h = _st(h, "h0pad")
     return h.transpose(1, 2)
 
 
@@ -153,16 +165,17 @@ def spectrogram_tokens(x: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, p_drop: 
     lm = stft_logmag(x, cfg.spec_n_fft, cfg.spec_hop_length, cfg.spec_freq_bins, sd.get(pre + "window"))
     img = lm.unsqueeze(1)
     h = F.conv2d(img, sd[pre + "spec_conv.0.weight"], sd[pre + "spec_conv.0.bias"], padding=1)
-    h = F.max_pool2d(torch.relu(h), 2)
-    h = F.conv2d(h, sd[pre + "spec_conv.3.weight"], sd[pre + "spec_conv.3.bias"], padding=1)
+    h = _st(F.max_pool2d(torch.relu(h), 2), "sp_p1")
+    h = _st(F.conv2d(h, sd[pre + "spec_conv.3.weight"], sd[pre + "spec_conv.3.bias"], padding=1), "sp_out2")
     if SPEC_CONV2_TAPS is not None:          # what a hook on spec_conv[3] sees (Grad-CAM, eeg_metrics.py:742-764)
         if h.requires_grad:
             h.retain_grad()
         SPEC_CONV2_TAPS.append(h)
-    h = F.adaptive_avg_pool2d(torch.relu(h), (4, 4)).flatten(1)
+    h = _st(F.adaptive_avg_pool2d(torch.relu(h), (4, 4)).flatten(1), "sp_pooled")
     h = torch.relu(F.linear(h, sd[pre + "proj.0.weight"], sd[pre + "proj.0.bias"]))
     if p_drop > 0:
         h = _dropout(h, p_drop, ("spec",))
+    h = _st(h, "sp_hp0")
     tok = F.linear(h, sd[pre + "proj.3.weight"], sd[pre + "proj.3.bias"]).reshape(B, C, cfg.d_model)
     return (tok, lm) if return_logmag else tok
 
@@ -253,9 +266,11 @@ def ibs_tokenize(conn: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, p_drop: flo
         var = x.var(1, unbiased=False, keepdim=True)
         x = (x - mu) / torch.sqrt(var + 1e-5)
         x = x * sd[pre + "instance_norm.weight"] + sd[pre + "instance_norm.bias"]
-    h = F.gelu(F.linear(x, sd[pre + "bottleneck.0.weight"], sd[pre + "bottleneck.0.bias"]))
+    x = _st(x, "ib_in")
+    h = F.gelu(_st(F.linear(x, sd[pre + "bottleneck.0.weight"], sd[pre + "bottleneck.0.bias"]), "ib_u"))
     if p_drop > 0:
         h = _dropout(h, p_drop, ("ibstok",))
+    h = _st(h, "ib_h")
     h = F.linear(h, sd[pre + "bottleneck.3.weight"], sd[pre + "bottleneck.3.bias"])
     return h + sd[pre + "type_embedding"]
 
@@ -308,13 +323,13 @@ def mha(q_in: Tensor, kv_in: Tensor, sd: Dict[str, Tensor], pre: str, H: int, p_
     """Multi-head scaled dot-product attention with separate q/k/v/out projections (A:202-213)."""
     B, Tq, D = q_in.shape
     dk = D // H
-    q = F.linear(q_in, sd[pre + "q_proj.weight"], sd[pre + "q_proj.bias"]).view(B, -1, H, dk).transpose(1, 2)
-    k = F.linear(kv_in, sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"]).view(B, -1, H, dk).transpose(1, 2)
-    v = F.linear(kv_in, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"]).view(B, -1, H, dk).transpose(1, 2)
+    q = _st(F.linear(q_in, sd[pre + "q_proj.weight"], sd[pre + "q_proj.bias"]), "qkv").view(B, -1, H, dk).transpose(1, 2)
+    k = _st(F.linear(kv_in, sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"]), "qkv").view(B, -1, H, dk).transpose(1, 2)
+    v = _st(F.linear(kv_in, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"]), "qkv").view(B, -1, H, dk).transpose(1, 2)
     s = (q @ k.transpose(-2, -1)) / math.sqrt(dk)
     p = torch.softmax(s, dim=-1)
-    pd = _dropout(p, p_attn, ("attn", pre))
-    ctx = (pd @ v).transpose(1, 2).reshape(B, Tq, D)
+    pd = _st(_dropout(p, p_attn, ("attn", pre)), "probs")
+    ctx = _st((pd @ v).transpose(1, 2).reshape(B, Tq, D), "ctx")
     out = F.linear(ctx, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
     return (out, p) if return_probs else out
 
@@ -328,12 +343,12 @@ def encoder(x: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, p_drop: float = 0.0
     for l in range(cfg.num_layers):
         pre = f"encoder.layers.{l}."
         h = mha(x, x, sd, pre + "mha.", cfg.num_heads, p_drop)
-        x = _ln(x + _dropout(h, p_drop, ("drop1", l)), sd, pre + "ln1.")
+        x = _st(_ln(_st(x + _dropout(h, p_drop, ("drop1", l)), "r1"), sd, pre + "ln1."), "y1")
         h = torch.relu(F.linear(x, sd[pre + "ffn.linear1.weight"], sd[pre + "ffn.linear1.bias"]))
-        h = _dropout(F.linear(_dropout(h, p_drop, ("ffn_a", l)), sd[pre + "ffn.linear2.weight"], sd[pre + "ffn.linear2.bias"]),
+        h = _dropout(F.linear(_st(_dropout(h, p_drop, ("ffn_a", l)), "hff"), sd[pre + "ffn.linear2.weight"], sd[pre + "ffn.linear2.bias"]),
                      p_drop, ("ffn_b", l))
-        x = _ln(x + _dropout(h, p_drop, ("drop2", l)), sd, pre + "ln2.")
-    return _ln(x, sd, "encoder.norm.")
+        x = _st(_ln(_st(x + _dropout(h, p_drop, ("drop2", l)), "r2"), sd, pre + "ln2."), "x")
+    return _st(_ln(x, sd, "encoder.norm."), "zn")
 
 
 def cross_brain_attention(z1: Tensor, z2: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, p_drop: float = 0.0,
@@ -341,10 +356,10 @@ def cross_brain_attention(z1: Tensor, z2: Tensor, sd: Dict[str, Tensor], cfg: Mo
     """Both directions share one MHA and one LN and read the pre-update z1, z2 (D:966-974)."""
     CTX["stream"] = 0
     c1, p1 = mha(z1, z2, sd, "cross_attn.cross_attn.", cfg.num_heads, p_drop, return_probs=True)
-    o1 = _ln(z1 + _dropout(c1, p_drop, ("xdrop1",)), sd, "cross_attn.norm.")
+    o1 = _st(_ln(_st(z1 + _dropout(c1, p_drop, ("xdrop1",)), "rx"), sd, "cross_attn.norm."), "zc")
     CTX["stream"] = 1
     c2, p2 = mha(z2, z1, sd, "cross_attn.cross_attn.", cfg.num_heads, p_drop, return_probs=True)
-    o2 = _ln(z2 + _dropout(c2, p_drop, ("xdrop1",)), sd, "cross_attn.norm.")
+    o2 = _st(_ln(_st(z2 + _dropout(c2, p_drop, ("xdrop1",)), "rx"), sd, "cross_attn.norm."), "zc")
     CTX["stream"] = 0
     if probs is not None:
         probs.extend([p1, p2])
@@ -397,9 +412,9 @@ def forward(eeg1: Tensor, eeg2: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, la
     S = seq1.shape[1]
     pos = sd["pos_embed.pos_embed.weight"][:S]          # A:120-126 (learned)
     CTX["stream"] = 0
-    z1 = encoder(seq1 + pos, sd, cfg, p)
+    z1 = encoder(_st(seq1 + pos, "x0"), sd, cfg, p)
     CTX["stream"] = 1
-    z2 = encoder(seq2 + pos, sd, cfg, p)
+    z2 = encoder(_st(seq2 + pos, "x0"), sd, cfg, p)
     CTX["stream"] = 0
     if stages is not None:
         stages.update(h1=h1, h2=h2, z1=z1, z2=z2)
@@ -417,11 +432,11 @@ def forward(eeg1: Tensor, eeg2: Tensor, sd: Dict[str, Tensor], cfg: ModelCfg, la
     cls1, cls2 = z1c[:, 0], z2c[:, 0]
     off = cfg.pool_offset
     mp1, mp2 = z1c[:, off:].mean(1), z2c[:, off:].mean(1)
-    comb = torch.cat([cls1 + cls2, cls1 * cls2, (cls1 - cls2).abs()], -1)            # D:933-938
+    comb = _st(torch.cat([cls1 + cls2, cls1 * cls2, (cls1 - cls2).abs()], -1), "comb")   # D:933-938
     f_pair = F.linear(comb, sd["symmetric_fusion.proj.weight"], sd["symmetric_fusion.proj.bias"])
-    zf = torch.cat([f_pair, mp1, mp2], -1)                                            # D:1212
+    zf = _st(torch.cat([f_pair, mp1, mp2], -1), "zf")                                 # D:1212
     hcl = torch.relu(F.linear(zf, sd["classifier.0.weight"], sd["classifier.0.bias"]))
-    hcl = _dropout(hcl, p, ("cls",))
+    hcl = _st(_dropout(hcl, p, ("cls",)), "hcl")
     logits = F.linear(hcl, sd["classifier.3.weight"], sd["classifier.3.bias"])
     out = {"logits": logits, "cls1": cls1, "cls2": cls2}
     if cfg.use_ibs:

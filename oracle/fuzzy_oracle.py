@@ -94,11 +94,14 @@ def temperature_regularization(p, t_min=0.5, t_max=5.0, eps_temp=0.1):
     return F.relu(Ti - t_max) + F.relu(t_min - Ti) + F.relu(Te - t_max) + F.relu(t_min - Te)
 
 
-def fusion_loop_loss(z_img, z_eeg, labels, p, mode, lam_img=0.3, lam_eeg=0.3, lam_reg=0.1, t_min=0.5, t_max=5.0):
+def fusion_loop_loss(z_img, z_eeg, labels, p, mode, lam_img=0.3, lam_eeg=0.3, lam_reg=0.1, t_min=0.5, t_max=5.0, parts=None):
     """The loss of the reference's multimodal step (train_multimodal_fuzzy_fusion.py:436-460); auxiliary terms use the
     DETACHED temperatures (aux_info['temperatures'] holds .detach()ed tensors, fuzzy_gating_fusion.py:334)."""
     import torch.nn.functional as F
     fused, alpha, (Ti, Te) = fuzzy_forward_torch(z_img, z_eeg, p, mode)
-    loss = (F.cross_entropy(fused, labels) + lam_img * F.cross_entropy(z_img / Ti.detach(), labels)
-            + lam_eeg * F.cross_entropy(z_eeg / Te.detach(), labels) + lam_reg * temperature_regularization(p, t_min, t_max))
+    ce, ai, ae = F.cross_entropy(fused, labels), F.cross_entropy(z_img / Ti.detach(), labels), F.cross_entropy(z_eeg / Te.detach(), labels)
+    reg = temperature_regularization(p, t_min, t_max)
+    loss = ce + lam_img * ai + lam_eeg * ae + lam_reg * reg
+    if parts is not None:           # the four terms the reference loop logs per step (:512-516)
+        parts.update(loss_ce=ce.detach(), loss_aux_img=ai.detach(), loss_aux_eeg=ae.detach(), loss_reg=reg.detach())
     return loss, fused, alpha

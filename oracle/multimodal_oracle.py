@@ -26,6 +26,18 @@ def image_logits(enc_cpu, img1, img2):
     return enc_cpu.head(torch.cat([f(img1), f(img2)], -1))
 
 
+def synthetic_gaze_state(module, seed: int):
+    """deterministic synthetic weights for the image branch (`cnn.*`, `head.*`), independent of torch's default-init RNG stream;
+    used by oracle/make_golden_mm_loop.py on the reference side and by the tests on this side"""
+    import numpy as np
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, v in module.state_dict().items():
+        fan = max(1, int(np.prod(v.shape[1:]))) if v.dim() > 1 else 1
+        sd[k] = (torch.randn(v.shape, generator=g) * (0.5 / np.sqrt(fan) if v.dim() > 1 else 0.02)).to(v.dtype)
+    return sd
+
+
 class Stepper:
     def __init__(self, gaze_cpu, eeg_cfg, eeg_sd, fusion_sd, mode, encoder_lr, fusion_lr, weight_decay, max_grad_norm, lams,
                  treg, warmup_steps, total_steps):
@@ -51,14 +63,16 @@ class Stepper:
         z_img = image_logits(self.gaze, img1, img2)
         z_eeg = O.forward(eeg1, eeg2, {**self.eeg, **self.buf}, self.cfg, labels)["logits"]
         li, le, lr_ = self.lams
-        loss, fused, alpha = FO.fusion_loop_loss(z_img, z_eeg, labels, self.fus, self.mode, li, le, lr_, *self.treg)
+        parts = {}
+        loss, fused, alpha = FO.fusion_loop_loss(z_img, z_eeg, labels, self.fus, self.mode, li, le, lr_, *self.treg, parts=parts)
         loss.backward()
         params = [p for g in self.opt.param_groups for p in g["params"]]
         grads = {"gaze": torch.cat([p.grad.reshape(-1) for p in self.gaze.parameters()]),
                  "eeg": {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for k, p in self.eeg.items()},
                  "fusion": {k: p.grad.clone() for k, p in self.fus.items()}}
         norm = torch.nn.utils.clip_grad_norm_(params, self.max_norm) if self.max_norm else None
+        lrs = [g["lr"] for g in self.opt.param_groups]
         self.opt.step()
         self.sched.step()
         return dict(loss=loss.detach(), fused=fused.detach(), alpha=alpha.detach(), z_img=z_img.detach(), z_eeg=z_eeg.detach(),
-                    grads=grads, norm=norm)
+                    grads=grads, norm=norm, lrs=lrs, **parts)

@@ -67,6 +67,8 @@ def main():
         ref = make("f32", 100)                           # rank 0's initialisation = what the broadcast distributed
         tr1 = MultimodalTrainer(ref, dev, **HP)
         tr1._reducers = lambda *a: None                  # single-process reference: no exchange
+        ref.eeg_encoder._flat.ensure(dev)
+        ref.gaze_encoder._flat.ensure(dev)
         start = [f.clone() for f in flats(tr1, ref)]
         for step in range(2):
             tr1.train_step(*(d(t_) for t_ in batch), dropout=False)

@@ -1,5 +1,5 @@
 """Manual (GPU box): measures the achieved parity errors of the HIP path against every reference-generated fixture and writes
-them as JSON (committed as profiles/r02_parity_table.json; the gates in tests/ are set to <= 2x these values).
+them as JSON (committed as profiles/r0N_parity_table.json; the gates in tests/ are set from these values).
 Per fixture x input kind x compute dtype: max |dlogit|, |dloss|, argmax agreement, cls1/cls2 relative error, and in f32 the
 worst per-parameter gradient error (norm-relative for every parameter, Frobenius-relative where the fixture holds full tensors).
 Plus the 512-sample logits fixture (argmax agreement overall and on decided samples)."""
@@ -79,10 +79,52 @@ def fixture_rows():
     return rows
 
 
-def logits512_rows():
+def sign_flip_rows():
+    """f32 mode, configurations with synchrony tokens: WHICH connectivity entries differ from the reference's, and by how much.
+    PLI = |mean_t sign(dphi_t)| (D:613-630): one sample whose sign flips (dphi within rounding of 0 or +-pi: the radix-2 LDS FFT
+    rounds differently from pocketfft) moves the signed mean by exactly 2/T (1/T through sign(0) = 0), so every PLI difference must sit on the
+    lattice k/T up to fp32 noise -- that is measured here per fixture, entry by entry; wPLI (power-weighted, D:632-658) moves by 2 w_t.
+    All other features (PLV, coherence, correlations, phase difference) are continuous and must agree to 1e-4."""
+    rows = []
+    T = 1024
+    for name in ("a5_full", "b1_no_inorm", "b2_phase", "b3_amplitude", "tiny_full", "a5_c32"):
+        for kind in ("randn", "gen_eeg"):
+            z, kw, cfg, sd, model = build(name, "f32")
+            model.eval()
+            x1, x2, labels = t(z[f"{kind}/eeg1"]).to(DEV), t(z[f"{kind}/eeg2"]).to(DEV), t(z["labels"]).to(DEV)
+            with torch.no_grad():
+                out = model(x1, x2, labels)
+            torch.cuda.synchronize()
+            eng = next(iter(model._engines.values()))
+            conn = eng.a["ib_conn"].cpu().numpy()[:2][:, :, cfg.feature_indices].astype(np.float64)
+            ref = z[f"{kind}/stage/connectivity"].astype(np.float64)
+            row = dict(fixture=name, kind=kind, entries_per_feature=int(conn[:, :, 0].size),
+                       max_abs_dlogit=float(np.abs(out["logits"].float().cpu().numpy() - z[f"{kind}/out/logits"]).max()))
+            for j, f in enumerate(cfg.feature_indices):
+                d = conn[:, :, j] - ref[:, :, j]
+                key = {0: "plv", 1: "pli", 2: "wpli", 3: "coherence", 4: "power_corr", 5: "phase_diff", 6: "time_corr"}.get(f, f"f{f}")
+                if f == 1:
+                    k = d * T                                           # in units of 1/T: a +1 <-> -1 flip is 2, a flip through sign(0) = 0 is 1
+                    moved = np.abs(d) > 1e-4
+                    row["pli"] = dict(entries_moved=int(moved.sum()), max_abs_diff=float(np.abs(d).max()),
+                                      max_shift_in_units_of_1_over_T=float(np.abs(np.round(k[moved])).max()) if moved.any() else 0.0,
+                                      max_distance_from_lattice_in_units_of_1_over_T=float(np.abs(k[moved] - np.round(k[moved])).max()) if moved.any() else 0.0,
+                                      max_abs_diff_of_unmoved=float(np.abs(d[~moved]).max()))
+                elif f == 2:
+                    moved = np.abs(d) > 1e-4
+                    row["wpli"] = dict(entries_moved=int(moved.sum()), max_abs_diff=float(np.abs(d).max()),
+                                       max_abs_diff_of_unmoved=float(np.abs(d[~moved]).max()))
+                else:
+                    row[key] = dict(max_abs_diff=float(np.abs(d).max()))
+            rows.append(row)
+            print(json.dumps(row), flush=True)
+    return rows
+
+
+def logits512_rows(dtypes=("f32", "bf16", "fp16")):
     rows = []
     for name in L512:
-        for dtype in ("f32", "bf16"):
+        for dtype in dtypes:
             got, ref, am, margin = run512(name, dtype)
             decided = margin > 4e-2
             agree = got.argmax(-1) == am
@@ -96,6 +138,7 @@ def logits512_rows():
 
 
 if __name__ == "__main__":
-    out = Path(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r02_parity_table.json")
-    res = {"device": torch.cuda.get_device_name(0), "fixtures": fixture_rows(), "logits512": logits512_rows()}
+    out = Path(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r03_parity_table.json")
+    res = {"device": torch.cuda.get_device_name(0), "logits512": logits512_rows(), "sign_flips": sign_flip_rows(),
+           "fixtures": fixture_rows()}
     out.write_text(json.dumps(res, indent=1))

@@ -21,7 +21,9 @@ def test_two_rank_multimodal_step(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(REPO / "tests" / "ddp_mm5_gpu_worker.py"), str(tmp_path)]
     res = subprocess.run(cmd, capture_output=True, text=True, cwd=str(REPO), timeout=900)
-    assert res.returncode == 0, res.stderr[-3000:]
+    # on failure show each rank's own traceback (torchrun's summary alone hides the root cause)
+    assert res.returncode == 0, "\n".join([ln for ln in res.stderr.splitlines() if "[rank0]" in ln][-40:]
+                                          + [ln for ln in res.stderr.splitlines() if "[rank1]" in ln][-25:]) + res.stderr[-1500:]
     r0 = json.loads((tmp_path / "rank0.json").read_text())
     r1 = json.loads((tmp_path / "rank1.json").read_text())
     for r in (r0, r1):

@@ -126,3 +126,50 @@ def test_warmup_cosine_equals_lambdalr():
         assert abs(opt.param_groups[0]["lr"] - warmup_cosine_factor(s, ws, ts)) < 1e-12
         opt.step()
         sched.step()
+
+
+def test_f32_loop_matches_the_reference_loop_fixture():
+    """tests/golden/mm_loop.npz = the REFERENCE's own train_one_epoch + optimizer / scheduler construction run on CPU
+    (oracle/make_golden_mm_loop.py): the HIP trainer must reproduce its epoch losses, per-step learning rates, clipped norms and
+    parameter updates over the same 2 x 4 steps."""
+    from tests.test_mm_loop_golden import fixture_batches, fixture_models, load_fixture
+    z, meta = load_fixture()
+    cfg, eeg_sd, gaze, fusion = fixture_models(meta)
+    eeg = DualEEGTransformer(**meta["eeg_kw"], compute_dtype="f32")
+    eeg.load_state_dict(eeg_sd)
+    model = MultimodalFusionModel(gaze, eeg, fusion)
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    t, fz = meta["config"]["training"], meta["config"]["fusion"]
+    spe = meta["n"] // meta["batch"]
+    tr = MultimodalTrainer(model, DEV, encoder_lr=t["encoder_learning_rate"], fusion_lr=t["fusion_learning_rate"],
+                           weight_decay=t["weight_decay"], max_grad_norm=t["max_grad_norm"], lambda_aux_img=t["lambda_aux_img"],
+                           lambda_aux_eeg=t["lambda_aux_eeg"], lambda_reg=t["lambda_reg"], temp_reg_min=fz["temp_reg_min"],
+                           temp_reg_max=fz["temp_reg_max"], warmup_steps=t["warmup_epochs"] * spe, total_steps=t["epochs"] * spe)
+    batches = fixture_batches(meta)
+    step = 0
+    for epoch in range(meta["epochs"]):
+        acc = {k: [] for k in ("loss", "loss_ce", "loss_aux_img", "loss_aux_eeg", "loss_reg")}
+        alphas = []
+        for b in batches:
+            out = tr.train_step(*(x.to(DEV) for x in b), dropout=False)
+            st = model.eeg_encoder.engine(meta["batch"], 1024, DEV).read_state()
+            assert abs(st.lr - float(z["lrs"][step][0])) <= 1e-7 * max(1e-9, float(z["lrs"][step][0])) + 1e-12, (step, st.lr)
+            assert abs(min(st.grad_norm, t["max_grad_norm"]) - float(z["clipped_grad_norm"][step])) < 2e-3, (step, st.grad_norm)
+            for k in acc:
+                acc[k].append(float(out[k]))
+            alphas.append(out["alpha"].cpu().numpy())
+            step += 1
+        for k in acc:
+            assert abs(np.mean(acc[k]) - float(z[f"epoch{epoch}/{k}"])) < 1e-4, (epoch, k, np.mean(acc[k]), float(z[f"epoch{epoch}/{k}"]))
+        assert abs(np.concatenate(alphas).mean() - float(z[f"epoch{epoch}/alpha_mean"])) < 2e-5
+    final = model.state_dict()
+    worst = 0.0
+    for i, n in enumerate(str(x) for x in z["param_names"]):
+        if n.endswith("k_proj.bias"):
+            continue      # the key bias has NO gradient (soft-max is shift-invariant): Adam turns its rounding noise into lr-sized steps
+        delta = (final[n].detach().cpu() - init[n].cpu()).double()
+        dn = float(z["delta_norm"][i])
+        worst = max(worst, abs(float(delta.norm()) - dn) / max(dn, 1e-9))
+        assert abs(float(delta.norm()) - dn) <= 2e-2 * dn + 1e-6, (n, float(delta.norm()), dn)
+        if n.startswith("fusion."):
+            np.testing.assert_allclose(final[n].detach().cpu().double().numpy(), z["final/" + n], rtol=0, atol=2e-4, err_msg=n)

@@ -141,7 +141,7 @@ def test_gemm_nt_dropout_and_gate(dtype):
     dx, dxd = torch.zeros_like(x), torch.zeros_like(x)
     part = torch.zeros(64 * 2 * N, device=DEV)
     dyr = torch.randn(M, N, generator=g).to(DT[dtype]).to(DEV)
-    call("eg_layernorm_bwd", ptr(dyr), ptr(x), ptr(stats), ptr(gam), ptr(dx), ptr(dxd), ptr(part), 64, M, N, dtype, 0.1, 5,
+    call("eg_layernorm_bwd", ptr(dyr), ptr(x), ptr(stats), ptr(gam), ptr(dx), ptr(dxd), ptr(part), 64, 64, M, N, dtype, 0.1, 5,
          0.0, 0, ptr(st), 0)
     torch.cuda.synchronize()
     assert torch.equal(dxd != 0, (d1 != 0) & (dx != 0)) or ((dxd != 0) ^ (d1 != 0)).float().mean() < 1e-3
@@ -201,7 +201,7 @@ def test_layernorm(dtype, D):
     nblk = 32
     part = torch.zeros(nblk * 2 * D, device=DEV)
     dyd = dy.to(DEV)
-    call("eg_layernorm_bwd", ptr(dyd), ptr(xd), ptr(stats), ptr(gamd), ptr(dx), 0, ptr(part), nblk, M, D, dtype, 0.0, 0, 0.0,
+    call("eg_layernorm_bwd", ptr(dyd), ptr(xd), ptr(stats), ptr(gamd), ptr(dx), 0, ptr(part), nblk, nblk, M, D, dtype, 0.0, 0, 0.0,
          0, 0, 0)
     dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
     call("eg_reduce_partials", ptr(part), ptr(dg), D, nblk, 2 * D, 0, 0)
@@ -608,7 +608,7 @@ def test_gemm_row_layernorm_backward(dtype, M, K, p):
     torch.testing.assert_close(part[:, 1].sum(0).cpu().double(), br.grad, rtol=2e-2 if dtype != L.EG_F32 else 1e-4, atol=0.3 if dtype != L.EG_F32 else 1e-3)
     # the dropout-masked copy uses the same (seed, site, element) mask as the stand-alone kernel
     dx2, dxd2, part2 = torch.zeros_like(dx), torch.zeros_like(dx), torch.zeros(512, 2, 256, device=DEV)
-    call("eg_layernorm_bwd", ptr(dy_out), ptr(x), ptr(stats), ptr(gamma), ptr(dx2), ptr(dxd2), ptr(part2), 512, M, 256, dtype,
+    call("eg_layernorm_bwd", ptr(dy_out), ptr(x), ptr(stats), ptr(gamma), ptr(dx2), ptr(dxd2), ptr(part2), 512, 512, M, 256, dtype,
          p, 5, 0.0, 0, ptr(st), 0)
     torch.cuda.synchronize()
     keep_a, keep_b = dxd.float().cpu() != 0, dxd2.float().cpu() != 0
