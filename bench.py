@@ -140,7 +140,7 @@ def cpu_baseline(kw, C, T, Bc=256, seconds_budget=30.0):
 
 
 ROUTES = {0: "gemm_nt_kernel", 1: "gemm_nt_wide_kernel", 2: "rs_gemm_kernel", 3: "gemm_nt_row_kernel", 4: "ffn_chain_kernel",
-          5: "gemm_nt_tall_kernel", 7: "ffn_chain_kernel (product 1 only: q|k|v)"}
+          5: "gemm_nt_tall_kernel", 7: "ffn_chain_kernel (product 1 only: q|k|v)", 8: "attn_block_fwd_kernel"}
 
 
 def roofline_from_probes(probes, nsteps_probed, dtype):

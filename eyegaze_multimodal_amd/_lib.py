@@ -65,6 +65,13 @@ class FfnDesc(C.Structure):
                 ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_out", C.c_void_p), ("ln_stats", C.c_void_p)]
 
 
+class AttnBlockDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("wqkv_frag", C.c_void_p), ("wo_frag", C.c_void_p), ("bqkv", C.c_void_p), ("bo", C.c_void_p),
+                ("qkv", C.c_void_p), ("ctx", C.c_void_p), ("lse", C.c_void_p), ("r1", C.c_void_p), ("state", C.c_void_p),
+                ("NB", C.c_int32), ("S", C.c_int32), ("d_model", C.c_int32), ("num_heads", C.c_int32), ("dtype", C.c_int32),
+                ("attn_drop_p", C.c_float), ("out_drop_p", C.c_float), ("attn_drop_site", C.c_uint32), ("out_drop_site", C.c_uint32)]
+
+
 class PackEntry(C.Structure):
     _fields_ = [("src", C.c_uint64), ("dst", C.c_uint64), ("rows", C.c_int32), ("cols", C.c_int32), ("ldd", C.c_int32),
                 ("mode", C.c_int32), ("blk0", C.c_int32), ("nblk", C.c_int32)]
@@ -102,6 +109,8 @@ SIGNATURES = {
     "eg_gemm_nt_route": [C.POINTER(GemmDesc)],
     "eg_frag_order_rows": [_P, _P, _I, _I, _I, _P],
     "eg_ffn_chain": [C.POINTER(FfnDesc), _P],
+    "eg_attn_block_fwd": [C.POINTER(AttnBlockDesc), _P],
+    "eg_attn_block_ok": [_I, _I, _I, _I],
     "eg_gemm_tn": [C.POINTER(GemmTNDesc), _P],
     "eg_reduce_partials": [_P, _P, _L, _I, _L, _I, _P],
     "eg_gemm_tn_grouped": [_P, _I, _I, _I, _I, _I, _P],

@@ -145,6 +145,29 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const eg_pack_entry* __
       const int c = c0 + i, r = r0 + tx;
       if (c < e.cols && r < e.rows) Elem<T>::st(dst + (size_t)c * e.ldd + r, tile[tx][i]);
     }
+  } else if (e.mode == 7 || e.mode == 8) {
+    // eg_attn_block_fwd's fragment order (16-bit dtypes), source fp32 [256, 256] = one of q_proj / k_proj / v_proj (mode 7, part
+    // e.ldd = 0 / 1 / 2 into the shared [chunk c: 4][wave: 4][k-step s: 8][tile j: 3][lane] image, tile t = 3 wave + j of the chunk
+    // = head t / 6, part (t % 6) / 2, half t % 2) or out_proj (mode 8: [chunk c: 4][wave: 4][k-step s: 2][tile j: 4][lane]).
+    const int u = lb * 256 + threadIdx.x;                  // 8192 chunks of 8 elements per [256, 256] source
+    const int lane = u & 63, l15 = lane & 15, g4 = lane >> 4;
+    int n, k0;
+    size_t q;
+    if (e.mode == 7) {
+      const int s8 = (u >> 6) & 7, half = (u >> 9) & 1, th = (u >> 10) & 1, c = u >> 11;
+      const int t = th * 6 + e.ldd * 2 + half, wn = t / 3, j = t % 3;
+      n = (2 * c + th) * 32 + 16 * half + l15; k0 = 32 * s8 + 8 * g4;
+      q = ((((size_t)c * 4 + wn) * 8 + s8) * 3 + j) * 64 + lane;
+    } else {
+      const int j = (u >> 6) & 3, s2 = (u >> 8) & 1, wn = (u >> 9) & 3, c = u >> 11;
+      n = 64 * wn + 16 * j + l15; k0 = 64 * c + 32 * s2 + 8 * g4;
+      q = (size_t)u;
+    }
+    if (u < 8192) {
+      float v[8];
+      load8(src + (size_t)n * 256 + k0, v);
+      if constexpr (sizeof(T) == 2) store8((T*)e.dst + q * 8, v);
+    }
   } else if (e.mode >= 3 && e.mode <= 6) {
     // MFMA-fragment order of eg_ffn_chain's weights: destination chunk q (8 elements) is what lane q%64 of a wave loads as
     // its operand of one v_mfma_f32_16x16x32, so a fragment load is ONE contiguous 1-KB read.  The logical matrix is the source

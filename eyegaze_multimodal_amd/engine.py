@@ -150,6 +150,7 @@ class Engine:
         if self.S > 160:
             raise L.EgError(f"sequence length {self.S} exceeds the attention core's limit of 160")
         self.M = self.NB * self.S
+        self._want_attn_block = os.environ.get("EYEGAZE_ATTN_BLOCK", "1") != "0"
         self.fp: FlatParams = model._flat
         self.stream = 0
         self.probes = {}   # tag -> (start_event, end_event) recorded around that launch
@@ -163,6 +164,9 @@ class Engine:
         # launch, step 3.716 vs 3.703 ms), so opt-in
         self.qkv_chain = os.environ.get("EYEGAZE_QKV_CHAIN", "0") == "1"
         self.cus = torch.cuda.get_device_properties(device).multi_processor_count if device.type == "cuda" else 256
+        # attention half of an encoder layer (q|k|v projection, attention core, out-proj + dropout + residual) as ONE launch with a
+        # workgroup per window (csrc/attnblock.hip): 16-bit compute dtypes, d_model == 256, 8 heads, S <= 80 (set after S is known)
+        self.attn_block = False
         # feed-forward pair as one launch (csrc/ffn.hip): 16-bit compute dtypes, d_model == 256, d_ff a multiple of 128
         self.fuse_ffn = (dtype != EG_F32 and cfg.d_model == 256 and cfg.d_ff % 128 == 0 and not self.fuse_ln
                          and os.environ.get("EYEGAZE_FFN", "1") != "0")
@@ -179,6 +183,8 @@ class Engine:
         if (self.M + 63) // 64 > 2048:
             self.fuse_ln = False      # the scratch partial buffer holds 2048 workgroups
         self.probe_all = None  # list of (start, end, flops) for every gemm_nt launch when bench.py enables it
+        self.attn_block = bool(self._want_attn_block and dtype != EG_F32 and not self.fuse_ln
+                               and L.lib().eg_attn_block_ok(self.S, cfg.d_model, cfg.num_heads, dtype))
         self._alloc()
         self.packed_version = -1
         self._recording = False
@@ -213,6 +219,9 @@ class Engine:
             w[f"bqkv{l}"] = self._t(3 * d, dtype=f32)
             if self.fuse_ffn and self.qkv_chain:      # q|k|v weights in eg_ffn_chain's fragment order (product-1-only form)
                 w[f"qkvf{l}"] = self._t(3 * d * d)
+            if self.attn_block and l != "x":          # eg_attn_block_fwd's fragment-ordered q|k|v and out-proj weights
+                w[f"wqkvb{l}"] = self._t(3 * d * d)
+                w[f"wob{l}"] = self._t(d * d)
             if l != "x":
                 w[f"w1{l}"] = self._t(F, d)
                 w[f"w1T{l}"] = self._t(d, F)
@@ -391,6 +400,29 @@ class Engine:
             self.ffn(ptr(x), ptr(self.w[f"qkvf{l}"]), 0, ptr(self.a[f"qkv{l}"]), 0, M, 3 * d, bias1=ptr(self.w[f"bqkv{l}"]))
         else:
             self.gemm(ptr(x), ptr(self.w[f"qkv{l}"]), ptr(self.a[f"qkv{l}"]), M, 3 * d, d, bias=ptr(self.w[f"bqkv{l}"]))
+
+    def attn_block_fwd(self, x, l, p, sites):
+        """eg_attn_block_fwd (csrc/attnblock.hip): A:202-213 + the residual of A:292-293 for encoder layer l in one launch"""
+        a, w, fp, d = self.a, self.w, self.fp, self.cfg.d_model
+        dsc = L.AttnBlockDesc()
+        dsc.x, dsc.wqkv_frag, dsc.wo_frag = ptr(x), ptr(w[f"wqkvb{l}"]), ptr(w[f"wob{l}"])
+        dsc.bqkv, dsc.bo = ptr(w[f"bqkv{l}"]), fp.p_ptr(f"encoder.layers.{l}.mha.out_proj.bias")
+        dsc.qkv, dsc.ctx, dsc.lse, dsc.r1 = ptr(a[f"qkv{l}"]), ptr(a[f"ctx{l}"]), ptr(a[f"lse{l}"]), ptr(a[f"r1_{l}"])
+        dsc.state = self.st_ptr
+        dsc.NB, dsc.S, dsc.d_model, dsc.num_heads, dsc.dtype = self.NB, self.S, d, self.cfg.num_heads, self.dtype
+        dsc.attn_drop_p, dsc.attn_drop_site = p, sites["attn"]
+        dsc.out_drop_p, dsc.out_drop_site = p, sites["drop1"]
+        probe = None
+        if self.probe_all is not None:      # bench.py: timed like the eg_gemm_nt launches, as its own kernel (route 8)
+            probe = self._probe_pair()
+            M, S, H = self.M, self.S, self.cfg.num_heads
+            flops = 2.0 * M * d * 3 * d + 2.0 * M * d * d + 4.0 * self.NB * H * S * S * (d // H)
+            nbytes = self.es * (M * d * 3 + M * 3 * d + 4 * d * d) + 4 * (self.NB * H * S + 4 * d)    # x, ctx, r1 | qkv | weights | lse, biases
+            self.probe_all.append((probe[0], probe[1], flops, float(nbytes), (M, 3 * d, d), 8))
+            probe[0].record(torch.cuda.current_stream(self.device))
+        call("eg_attn_block_fwd", C.byref(dsc), self.stream)
+        if probe:
+            probe[1].record(torch.cuda.current_stream(self.device))
 
     def _probe_pair(self):
         """A (start, end) event pair for a timed launch: from bench.py's pre-created pool when there is one -- creating a
@@ -761,10 +793,11 @@ class Engine:
         if self._recording:
             self._plan.append((src, dst, R, Cc, ldd, 1))
 
-    def p_frag(self, src, dst, R, Cc, mode):
-        """eg_ffn_chain's fragment order of the fp32 parameter src [R, Cc] (eg_pack_table modes 3-6)."""
+    def p_frag(self, src, dst, R, Cc, mode, part=0):
+        """fragment order of the fp32 parameter src [R, Cc]: eg_ffn_chain's (eg_pack_table modes 3-6) or eg_attn_block_fwd's
+        (mode 7 with part = 0 / 1 / 2 for q / k / v_proj, mode 8 for out_proj)."""
         if self._recording:
-            self._plan.append((src, dst, R, Cc, 0, mode))
+            self._plan.append((src, dst, R, Cc, part, mode))
 
     def pack_params(self):
         key = (self.fp.flat.data_ptr(), self.stream)
@@ -807,6 +840,10 @@ class Engine:
                     self.p_frag(fp.p_ptr(f"{pre}{n}.weight"), ptr(w[f"qkvf{l}"]) + i * d * d * self.es, d, d, 3)
             self.p_cast(fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"o{l}"]), d * d)
             self.p_transpose(fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"oT{l}"]), d, d, d)
+            if self.attn_block and l != "x":
+                for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                    self.p_frag(fp.p_ptr(f"{pre}{n}.weight"), ptr(w[f"wqkvb{l}"]), d, d, 7, part=i)
+                self.p_frag(fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"wob{l}"]), d, d, 8)
 
         for l in range(cfg.num_layers):
             pre = f"encoder.layers.{l}."
@@ -866,12 +903,16 @@ class Engine:
         for l in range(cfg.num_layers):
             pre, sites = f"encoder.layers.{l}.", _layer_sites(l)
             x = a[f"x{l}"]
-            self.qkv_proj(x, l)
-            call("eg_attention_fwd", ptr(a[f"qkv{l}"]), ptr(a[f"ctx{l}"]), ptr(a[f"lse{l}"]), NB, S, H, 0, self.dtype, p,
-                 sites["attn"], self.st_ptr, st)
-            self._probs_hook(self.model.encoder.layers[l].mha.dropout, a[f"qkv{l}"], a[f"lse{l}"], 0)
-            self.gemm(ptr(a[f"ctx{l}"]), ptr(w[f"o{l}"]), ptr(a[f"r1_{l}"]), M, d, d, bias=fp.p_ptr(pre + "mha.out_proj.bias"),
-                      drop1=(p, sites["drop1"]), residual=ptr(x), ln=self._ln_f(pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"]))
+            if self.attn_block:     # q|k|v projection + attention core + out-proj / dropout / residual: one launch, a workgroup per window
+                self.attn_block_fwd(x, l, p, sites)
+                self._probs_hook(self.model.encoder.layers[l].mha.dropout, a[f"qkv{l}"], a[f"lse{l}"], 0)
+            else:
+                self.qkv_proj(x, l)
+                call("eg_attention_fwd", ptr(a[f"qkv{l}"]), ptr(a[f"ctx{l}"]), ptr(a[f"lse{l}"]), NB, S, H, 0, self.dtype, p,
+                     sites["attn"], self.st_ptr, st)
+                self._probs_hook(self.model.encoder.layers[l].mha.dropout, a[f"qkv{l}"], a[f"lse{l}"], 0)
+                self.gemm(ptr(a[f"ctx{l}"]), ptr(w[f"o{l}"]), ptr(a[f"r1_{l}"]), M, d, d, bias=fp.p_ptr(pre + "mha.out_proj.bias"),
+                          drop1=(p, sites["drop1"]), residual=ptr(x), ln=self._ln_f(pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"]))
             if not self.fuse_ln:
                 self.ln_fwd(a[f"r1_{l}"], pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"])
             if self.fuse_ffn:       # linear1 -> ReLU -> dropout -> linear2 -> dropout x2 -> + residual in one launch (A:272, A:294)

@@ -104,7 +104,8 @@ int eg_window_normalize(const float* raw, float* eeg1, float* eeg2, int N, int C
  * blocks [blk0, blk0 + nblk): mode 0 cast (1024 elements per block), 1 transpose-cast (one 32x32 tile per block),
  * 2 fp32 copy (fused bias vectors); 3-6 eg_ffn_chain's MFMA-fragment order of a 16-bit weight (2048 elements per block; the
  * source is fp32 [rows, cols]): 3 role 1 = src [F, 256], 4 role 1 = src^T (src [256, F]), 5 role 2 = src [256, F],
- * 6 role 2 = src^T (src [F, 256]); see eg_ffn_desc.  src / dst are absolute device addresses. */
+ * 6 role 2 = src^T (src [F, 256]); see eg_ffn_desc; 7 / 8 eg_attn_block_fwd's fragment order of a [256, 256] projection weight
+ * (7: q / k / v_proj with ldd = 0 / 1 / 2, 8: out_proj; 2048 elements per block).  src / dst are absolute device addresses. */
 typedef struct eg_pack_entry {
   uint64_t src, dst;
   int32_t rows, cols, ldd, mode, blk0, nblk;
@@ -216,6 +217,33 @@ typedef struct eg_ffn_desc {
 } eg_ffn_desc;
 int eg_ffn_chain(const eg_ffn_desc* d, void* stream);
 int64_t eg_ffn_gate_bits_bytes(int M, int F);
+
+/* ---------------------------------------------------------------------------------------------
+ * eg_attn_block_fwd — the attention half of a post-LN encoder layer in ONE launch, a workgroup per WINDOW (S <= 80 rows):
+ *   q|k|v = x Wqkv^T + b (A:203-205) -> softmax(q k^T / sqrt(32)), attention dropout, P v per head (A:206-212) ->
+ *   r1 = x + dropout(ctx Wo^T + bo) (A:213, A:292-293's residual; the LayerNorm stays eg_layernorm_fwd).
+ *   Stored: qkv [NB*S, 768], lse [NB, 8, S], ctx [NB*S, 256] (what eg_attention_bwd and the weight gradients read) and r1.
+ *   Bit-identical to eg_gemm_nt (q|k|v) -> eg_attention_fwd (kv_shift 0) -> eg_gemm_nt (out-proj, drop1 = out_drop, residual x).
+ *   16-bit dtypes, d_model == 256, 8 heads; rows contiguous (stride 256 / 768).  Weights in fragment order: wqkv_frag by three
+ *   eg_pack_table entries of mode 7 (ldd = 0, 1, 2 for q_proj, k_proj, v_proj, same dst), wo_frag by one entry of mode 8.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct eg_attn_block_desc {
+  const void* x;          /* [NB*S, 256] */
+  const void* wqkv_frag;  /* 768 x 256 elements, eg_pack_table mode 7 */
+  const void* wo_frag;    /* 256 x 256 elements, eg_pack_table mode 8 */
+  const float* bqkv;      /* [768] = q_proj.bias | k_proj.bias | v_proj.bias */
+  const float* bo;        /* [256] */
+  void* qkv;              /* out [NB*S, 768] */
+  void* ctx;              /* out [NB*S, 256] */
+  float* lse;             /* out [NB, 8, S] */
+  void* r1;               /* out [NB*S, 256] */
+  const eg_step_state* state;
+  int32_t NB, S, d_model, num_heads, dtype;
+  float attn_drop_p, out_drop_p;
+  uint32_t attn_drop_site, out_drop_site;
+} eg_attn_block_desc;
+int eg_attn_block_fwd(const eg_attn_block_desc* d, void* stream);
+int eg_attn_block_ok(int S, int d_model, int num_heads, int dtype);   /* 1 when eg_attn_block_fwd serves this geometry */
 
 /* ---------------------------------------------------------------------------------------------
  * eg_gemm_tn — weight-gradient product  dW[N,K] = sum_m dY[m,n] * X[m,k]  (fp32 result)
