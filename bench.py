@@ -111,7 +111,7 @@ def cpu_baseline(kw, C, T, Bc=256, seconds_budget=30.0):
     1 warm-up step, then up to 3 timed steps inside a bounded time budget)."""
     from oracle import dual_eeg_oracle as O
     from eyegaze_multimodal_amd.data import randn_windows
-    cores = min(16, len(os.sched_getaffinity(0)))  # the GPU box grants a 16-core share per GPU
+    cores = len(os.sched_getaffinity(0))            # every core this process may run on (BASELINE.md §4: all cores, count stated)
     torch.set_num_threads(cores)
     cfg = O.ModelCfg(in_channels=C, max_len=T // 4, **kw)
     sd = O.synthetic_state_dict(cfg, seed=1)
@@ -135,12 +135,13 @@ def cpu_baseline(kw, C, T, Bc=256, seconds_budget=30.0):
         step(n + 1)
         n += 1
     dt = (time.perf_counter() - t0) / n
-    return {"value": round(Bc / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(Bc / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "cores_available": os.cpu_count(),
+            "kind": "port",
             "sample": f"oracle fwd+bwd+clip+AdamW, train mode, B={Bc} windows of the same synthetic workload, {n} timed steps after 1 warm-up"}
 
 
 ROUTES = {0: "gemm_nt_kernel", 1: "gemm_nt_wide_kernel", 2: "rs_gemm_kernel", 3: "gemm_nt_row_kernel", 4: "ffn_chain_kernel",
-          5: "gemm_nt_tall_kernel", 7: "ffn_chain_kernel (product 1 only: q|k|v)", 8: "attn_block_fwd_kernel"}
+          8: "attn_block_fwd_kernel"}
 
 
 def roofline_from_probes(probes, nsteps_probed, dtype):
@@ -187,6 +188,64 @@ def roofline_from_probes(probes, nsteps_probed, dtype):
             "mfma": {"achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4)},
             "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)},
             "dominant_by_bound": by_bound, "eg_gemm_nt_by_kernel": by_kernel}
+
+
+def attach_traffic(roof, workload, dtype, B):
+    """`roofline.traffic` = HBM bytes per launch of the dominant kernel from the PMC counters.  FETCH_SIZE and WRITE_SIZE cannot share
+    a rocprofv3 pass (and never ride along with a timed run), so the value is NOT measured by this run: it is read from the newest
+    committed collection of this command (profiles/collect_r03.sh: separate --pmc passes, KiB -> B, FETCH x2 per the gfx950
+    correction), and `traffic_source` says which file, collected when, for which kernel."""
+    import datetime
+    if B != 256:
+        return
+    for rnd in ("r03", "r02"):
+        f = REPO / "profiles" / f"{rnd}_pmc_{workload}_{dtype}.json"
+        if not f.exists():
+            continue
+        recs = json.loads(f.read_text())
+        for rec in (recs if isinstance(recs, list) else [recs]):
+            if roof["kernel"].startswith(rec.get("kernel", "?")):
+                roof["traffic"] = rec.get("hbm_bytes_per_launch")
+                roof["traffic_source"] = {"file": f"profiles/{f.name}", "collected": rec.get("collected") or
+                                          datetime.date.fromtimestamp(f.stat().st_mtime).isoformat(), "kernel": rec.get("kernel"),
+                                          "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command "
+                                                 "(not measured by this run)"}
+                return
+    roof["traffic_source"] = None
+
+
+def f32_leg(ctor, B, C, T, dev, steps=5, warmup=2):
+    """The reference's own precision (train_art.py:170-222 runs fp32) beside the headline dtype: a few timed steps of the same
+    step in compute_dtype='f32' (exact-fp32 MFMA path), so the driver's record carries it."""
+    from eyegaze_multimodal_amd import HipAdamW
+    from eyegaze_multimodal_amd.data import randn_windows
+    torch.manual_seed(42)
+    model = ctor("f32").to(dev)
+    model.train()
+    eng = model.engine(B, T, dev)
+    opt = HipAdamW(model, lr=1e-4, weight_decay=0.01)
+    x1, x2, labels = randn_windows(B, C, T, seed=1234, num_classes=3, device=dev)
+    one = torch.ones(1, device=dev)
+
+    def step(i):
+        opt.begin_step(eng, seed=2000 + i)
+        eng.forward(x1, x2, labels, train=True)
+        eng.backward(gloss=one, gloss_ibs=(one if model.cfg.use_ibs else None))
+        opt.step(eng)
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    loss = float(eng.a["loss"])
+    assert loss == loss
+    del eng, opt, model
+    torch.cuda.empty_cache()
+    return {"dtype": "f32", "value": round(B / dt, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt, 4), "steps": steps,
+            "warmup": warmup, "note": "same step at the reference's precision (exact-fp32 MFMA path), secondary to the headline dtype"}
 
 
 def run_mm5(args, dev, world=1, rank=0, use_dist=False):
@@ -269,7 +328,7 @@ def cpu_baseline_mm5(tr, C, T, F_, W_, Bc=256, seconds_budget=30.0):
     from oracle import dual_eeg_oracle as O
     from oracle.multimodal_oracle import Stepper
     from eyegaze_multimodal_amd.train_multimodal_fuzzy_fusion import synth_multimodal
-    cores = min(16, len(os.sched_getaffinity(0)))
+    cores = len(os.sched_getaffinity(0))
     torch.set_num_threads(cores)
     m = tr.model
     gaze = copy.deepcopy(m.gaze_encoder).cpu().float()
@@ -288,7 +347,7 @@ def cpu_baseline_mm5(tr, C, T, F_, W_, Bc=256, seconds_budget=30.0):
         st.step(*batch)
         n += 1
     dt = (time.perf_counter() - t0) / n
-    return {"value": round(Bc / dt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+    return {"value": round(Bc / dt, 3), "unit": "samples/s", "cores": cores, "cores_available": os.cpu_count(), "kind": "port",
             "sample": f"multimodal oracle step (image CNN + EEG oracle + fuzzy fusion + clip + AdamW), eval-mode dropout, B={Bc}, "
                       f"{n} timed steps after 1 warm-up"}
 
@@ -335,6 +394,7 @@ def main():
                          "on the compute stream (sync) or double-buffered on a copy stream (overlap)")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: run the RCCL path with a single rank")
     ap.add_argument("--cpu-batch", type=int, default=256, help="batch of the CPU baseline leg (SURVEY 8d: 256)")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the secondary f32 measurement (the reference's precision)")
     ap.add_argument("--plan-only", action="store_true",
                     help="rehearsal without a GPU: form the process group, report world/rank and exit (CPU test of the launcher)")
     args = ap.parse_args()
@@ -392,7 +452,8 @@ def main():
     kw = dict(kw, num_classes=3)
     C = kw.pop("in_channels", 8)
     torch.manual_seed(42)
-    model = DualEEGTransformer(in_channels=C, max_len=T // 4, compute_dtype=args.dtype, **kw).to(dev)
+    ctor = lambda dt_: DualEEGTransformer(in_channels=C, max_len=T // 4, compute_dtype=dt_, **kw)
+    model = ctor(args.dtype).to(dev)
     model.train()
     eng = model.engine(B, T, dev)
     fp = model._flat
@@ -516,11 +577,7 @@ def main():
         roof = roofline_from_probes(probes, nsteps_probed, args.dtype)
         # HBM traffic per launch of the dominant kernel comes from the separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE
         # cannot share a pass, profiles/collect_r02.sh); the file names the kernel it was measured on.
-        pmc = REPO / "profiles" / f"r02_pmc_{args.workload}_{args.dtype}.json"
-        if pmc.exists() and B == 256:
-            rec = json.loads(pmc.read_text())
-            if roof["kernel"].startswith(rec.get("kernel", "?")):
-                roof["traffic"] = rec.get("hbm_bytes_per_launch")
+        attach_traffic(roof, args.workload, args.dtype, B)
         per_step = len(probes) // nsteps_probed
         if args.probe_dump:
             rows = []
@@ -542,6 +599,8 @@ def main():
                        "final_loss": round(loss, 5)},
             "roofline": roof,
         }
+        if world == 1 and args.dtype != "f32" and not args.no_f32_leg and not args.no_cpu_baseline and args.h2d == "none":
+            out["f32"] = f32_leg(ctor, B, C, T, dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(kw, C, T, Bc=args.cpu_batch)
         emit(out)

@@ -45,11 +45,7 @@ class GemmDesc(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldw", C.c_int32),
                 ("act", C.c_int32), ("dtype", C.c_int32),
                 ("drop1_p", C.c_float), ("drop2_p", C.c_float), ("drop1_site", C.c_uint32), ("drop2_site", C.c_uint32),
-                ("gate_scale", C.c_float), ("a_seg_len", C.c_int32), ("a_seg_stride", C.c_int64),
-                ("ln_mode", C.c_int32), ("row_tile", C.c_int32), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
-                ("ln_x", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_out", C.c_void_p), ("ln_out2", C.c_void_p),
-                ("ln_partial", C.c_void_p), ("ln_drop1_p", C.c_float), ("ln_drop2_p", C.c_float),
-                ("ln_drop1_site", C.c_uint32), ("ln_drop2_site", C.c_uint32), ("W_frag", C.c_void_p)]
+                ("gate_scale", C.c_float), ("a_seg_len", C.c_int32), ("a_seg_stride", C.c_int64)]
 
 
 class FfnDesc(C.Structure):
@@ -61,8 +57,7 @@ class FfnDesc(C.Structure):
                 ("M", C.c_int32), ("F", C.c_int32), ("act1", C.c_int32), ("dtype", C.c_int32),
                 ("drop_h_p", C.c_float), ("drop_c1_p", C.c_float), ("drop_c2_p", C.c_float),
                 ("drop_h_site", C.c_uint32), ("drop_c1_site", C.c_uint32), ("drop_c2_site", C.c_uint32),
-                ("gate_scale", C.c_float),
-                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_out", C.c_void_p), ("ln_stats", C.c_void_p)]
+                ("gate_scale", C.c_float)]
 
 
 class AttnBlockDesc(C.Structure):
@@ -107,7 +102,6 @@ SIGNATURES = {
     "eg_pack_convT_weight": [_P, _P, _I, _I, _I, _I, _I, _P],
     "eg_gemm_nt": [C.POINTER(GemmDesc), _P],
     "eg_gemm_nt_route": [C.POINTER(GemmDesc)],
-    "eg_frag_order_rows": [_P, _P, _I, _I, _I, _P],
     "eg_ffn_chain": [C.POINTER(FfnDesc), _P],
     "eg_attn_block_fwd": [C.POINTER(AttnBlockDesc), _P],
     "eg_attn_block_ok": [_I, _I, _I, _I],

@@ -44,7 +44,6 @@ template <typename T>
 struct FfnArgs {
   const T* A; const T* W1; const T* W2; T* H; T* C; const float* bias1; const float* bias2; const T* gate; const T* residual;
   const unsigned long long* bits_in; unsigned long long* bits_out;
-  const float* ln_gamma; const float* ln_beta; T* ln_out; float* ln_stats;      // LNF: LayerNorm of the stored C rows
   const eg_step_state* st;
   long long lda, ldh, ldc, ldg, ldr;
   int M, F, relu, res_in_lds;
@@ -64,7 +63,7 @@ template <typename T> __device__ __forceinline__ u32x2 f_pack4(const float v[4])
   return o;
 }
 
-template <typename T, int GATE, int BOUT, int LNF, int P2>
+template <typename T, int GATE, int BOUT>
 __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   typedef typename H16<T>::frag frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -108,10 +107,8 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   };
 #pragma unroll
   for (int s = 0; s < 4; ++s) req_w1(0, s, s);
-  if (P2) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) req_w2(0, s, s);
-  }
+  for (int s = 0; s < 2; ++s) req_w2(0, s, s);
 
   f32x4 acc2[5][4];
 #pragma unroll
@@ -128,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   //      chunks' 128-B lines here, where the wave waits for its HBM-resident A rows anyway: by the time chunk 1 is needed the
   //      lines sit in the memory-side cache, one XCD's L2 miss away. ----
   uint32_t touched = 0;
-  if (wn < (P2 ? 2 : 1)) {
+  if (wn < 2) {
     const char* wb = (const char*)(wn == 0 ? p.W1 : p.W2);
     const int lines = p.F * FD * 2 / 128;                    // per matrix
     const int per = (lines + gridDim.x - 1) / gridDim.x;
@@ -250,7 +247,6 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
     }
 
     // ---- product 2: acc2[i][j] += sum_h W2[col][h] * H[row][h] over the chunk's 128 hidden columns ----
-    if (P2) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       frag hf[5];
@@ -263,9 +259,7 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
       if (s < 2) req_w2(c, s + 2, s & 1);
       else if (c + 1 < nch) req_w2(c + 1, s - 2, s & 1);
     }
-    }
   }
-  if (!P2) return;          // product 1 only (e.g. the fused q|k|v projection): H is the result
   __syncthreads();          // every wave has left the chunk buffers: they become the fp32 image of the final epilogue
 
   // ---- epilogue 2: per 16-row tile through a wave-private fp32 image [16][68]; a lane then owns 16 consecutive columns of a row ----
@@ -291,11 +285,6 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
       eraw[i][1] = *(const u32x4*)(pe + 8);
     }
   }
-  float keep[LNF ? 5 : 1][16];                     // LNF: the rows as stored (rounded), for the LayerNorm below
-#pragma unroll
-  for (int i = 0; i < (LNF ? 5 : 1); ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) keep[i][j] = 0.f;
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const int m = m0 + 16 * i + er;
@@ -327,52 +316,6 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
       T* pc = p.C + (size_t)m * (size_t)p.ldc + n;
       store8(pc, v);
       store8(pc + 8, v + 8);
-      if (LNF) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) keep[i][j] = round_store<T>(v[j]);
-      }
-    }
-  }
-  if (LNF) {
-    // ---- LayerNorm (eps 1e-5) of the rows just stored, A:295: the workgroup owns whole rows, spread over its four waves.
-    //      Two-pass statistics through LDS (mean, then the centred sum of squares), partials combined in a fixed order ----
-    float* red = (float*)(hb + 32 * 1024);                   // [80 rows][4 waves], behind the waves' fp32 images
-    float mean[5], rstd[5];
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { const float dlt = pass ? keep[i][j] - mean[i] : keep[i][j]; s += pass ? dlt * dlt : dlt; }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        if (ec == 0) red[(16 * i + er) * 4 + wn] = s;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const f32x4 r4 = *(const f32x4*)(red + (16 * i + er) * 4);
-        const float tot = ((r4[0] + r4[1]) + r4[2]) + r4[3];
-        if (pass == 0) mean[i] = tot * (1.0f / 256.f); else rstd[i] = rsqrtf(tot * (1.0f / 256.f) + 1e-5f);
-      }
-      __syncthreads();
-    }
-    float gm[16], bt[16];
-    load8(p.ln_gamma + n, gm); load8(p.ln_gamma + n + 8, gm + 8);
-    load8(p.ln_beta + n, bt);  load8(p.ln_beta + n + 8, bt + 8);
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int m = m0 + 16 * i + er;
-      if (m < p.M) {
-        float y[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) y[j] = (keep[i][j] - mean[i]) * rstd[i] * gm[j] + bt[j];
-        T* py = p.ln_out + (size_t)m * (size_t)p.ldc + n;
-        store8(py, y);
-        store8(py + 8, y + 8);
-        if (p.ln_stats && wn == 0 && ec == 0) { p.ln_stats[2 * m] = mean[i]; p.ln_stats[2 * m + 1] = rstd[i]; }
-      }
     }
   }
 }
@@ -382,7 +325,6 @@ static int ffn_launch(const eg_ffn_desc* d, hipStream_t s) {
   FfnArgs<T> p;
   p.A = (const T*)d->A; p.W1 = (const T*)d->W1; p.W2 = (const T*)d->W2; p.H = (T*)d->H; p.C = (T*)d->C;
   p.bits_in = (const unsigned long long*)d->gate_bits_in; p.bits_out = (unsigned long long*)d->gate_bits_out;
-  p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_out = (T*)d->ln_out; p.ln_stats = d->ln_stats;
   p.bias1 = d->bias1; p.bias2 = d->bias2; p.gate = (const T*)d->gate; p.residual = (const T*)d->residual; p.st = d->state;
   p.lda = d->lda; p.ldh = d->ldh; p.ldc = d->ldc; p.ldg = d->ldg; p.ldr = d->ldr;
   p.M = d->M; p.F = d->F;
@@ -393,19 +335,17 @@ static int ffn_launch(const eg_ffn_desc* d, hipStream_t s) {
   p.dc2 = make_drop(d->drop_c2_p, d->drop_c2_site);
   p.gate_scale = d->gate_scale == 0.f ? 1.0f : d->gate_scale;
   const dim3 grid((d->M + FR - 1) / FR);
-#define FFN_LAUNCH(G_, B_, L_, P_)                                                                                                 \
+#define FFN_LAUNCH(G_, B_)                                                                                             \
   do {                                                                                                                 \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      (void)hipFuncSetAttribute((const void*)ffn_chain_kernel<T, G_, B_, L_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS); \
+      (void)hipFuncSetAttribute((const void*)ffn_chain_kernel<T, G_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS); \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((ffn_chain_kernel<T, G_, B_, L_, P_>), grid, dim3(256), F_LDS, s, p);                                                        \
+    hipLaunchKernelGGL((ffn_chain_kernel<T, G_, B_>), grid, dim3(256), F_LDS, s, p);                                   \
   } while (0)
-  if (!d->W2) FFN_LAUNCH(0, 0, 0, 0);
-  else if (d->gate_bits_in) FFN_LAUNCH(2, 0, 0, 1); else if (d->gate) FFN_LAUNCH(1, 0, 0, 1);
-  else if (d->ln_out) { if (d->gate_bits_out) FFN_LAUNCH(0, 1, 1, 1); else FFN_LAUNCH(0, 0, 1, 1); }
-  else if (d->gate_bits_out) FFN_LAUNCH(0, 1, 0, 1); else FFN_LAUNCH(0, 0, 0, 1);
+  if (d->gate_bits_in) FFN_LAUNCH(2, 0); else if (d->gate) FFN_LAUNCH(1, 0);
+  else if (d->gate_bits_out) FFN_LAUNCH(0, 1); else FFN_LAUNCH(0, 0);
 #undef FFN_LAUNCH
   EG_LAUNCH_CHECK("ffn_chain");
   return 0;
@@ -414,21 +354,16 @@ static int ffn_launch(const eg_ffn_desc* d, hipStream_t s) {
 }  // namespace
 
 extern "C" int eg_ffn_chain(const eg_ffn_desc* d, void* stream) {
-  EG_CHECK(d && d->A && d->W1 && d->H, "eg_ffn_chain: null operand");
-  EG_CHECK((d->W2 != nullptr) == (d->C != nullptr), "eg_ffn_chain: W2 and C go together (both NULL: product 1 only)");
-  EG_CHECK(d->W2 || !(d->gate || d->gate_bits_in || d->gate_bits_out || d->ln_out || d->residual),
-           "eg_ffn_chain: the product-1-only form takes bias1 / act1 / drop_h only");
+  EG_CHECK(d && d->A && d->W1 && d->W2 && d->H && d->C, "eg_ffn_chain: null operand");
   EG_CHECK(d->dtype == EG_BF16 || d->dtype == EG_F16, "eg_ffn_chain: 16-bit compute dtypes only (got %d)", d->dtype);
   EG_CHECK(d->M > 0 && d->F > 0 && d->F % FC == 0, "eg_ffn_chain: M=%d, F=%d (F must be a multiple of %d)", d->M, d->F, FC);
   EG_CHECK(d->act1 == EG_ACT_NONE || d->act1 == EG_ACT_RELU, "eg_ffn_chain: act1 %d", d->act1);
-  EG_CHECK(d->lda >= FD && (!d->C || d->ldc >= FD) && d->ldh >= d->F && d->lda % 8 == 0 && d->ldc % 8 == 0 && d->ldh % 8 == 0,
+  EG_CHECK(d->lda >= FD && d->ldc >= FD && d->ldh >= d->F && d->lda % 8 == 0 && d->ldc % 8 == 0 && d->ldh % 8 == 0,
            "eg_ffn_chain: row strides must be 16-B multiples covering the rows");
   EG_CHECK(!d->gate || (d->ldg >= d->F && d->ldg % 4 == 0), "eg_ffn_chain: gate stride");
   EG_CHECK(!(d->gate_bits_out && (d->gate_bits_in || d->gate)), "eg_ffn_chain: a launch either writes gate bits or applies a gate");
   EG_CHECK(((uintptr_t)d->gate_bits_in | (uintptr_t)d->gate_bits_out) % 8 == 0, "eg_ffn_chain: gate bit words must be 8-B aligned");
   EG_CHECK(!d->residual || (d->ldr >= FD && d->ldr % 8 == 0), "eg_ffn_chain: residual stride");
-  EG_CHECK(!d->ln_out || (d->ln_gamma && d->ln_beta && !d->gate && !d->gate_bits_in && (uintptr_t)d->ln_out % 16 == 0),
-           "eg_ffn_chain: ln_out needs ln_gamma and ln_beta (forward form only)");
   EG_CHECK((long long)d->M * d->F < (1ll << 32), "eg_ffn_chain: M*F exceeds the 32-bit dropout index");
   const float ps[3] = {d->drop_h_p, d->drop_c1_p, d->drop_c2_p};
   for (float q : ps) EG_CHECK(q >= 0.f && q < 1.f, "eg_ffn_chain: dropout p");

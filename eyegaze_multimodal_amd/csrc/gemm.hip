@@ -227,238 +227,6 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmNT<T> p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Row-complete NT GEMM for N == 256 (= d_model): a workgroup owns 64 WHOLE output rows (4 waves side by side, 64 columns
-// each), so the LayerNorm that follows the product in the model (A:293,295 forward; its backward after the FFN-1 /
-// q|k|v backward-data products) runs in the epilogue instead of a second pass over HBM:
-//   ln_mode 1: v = <gemm_nt epilogue>; C = v; ln_out = LayerNorm(v) (statistics of the STORED, i.e. rounded, row);
-//              stats[m] = (mean, rstd)
-//   ln_mode 2: dy = <gemm_nt epilogue> (C optional); LayerNorm backward against the saved row ln_x and stats:
-//              ln_out = dx, ln_out2 = dropout(dx) (the branch gradient), partial[block] = (sum dy*xhat | sum dy) per column
-// The A rows are read once (the 128x128 tiling reads them once per n-tile); the whole [256, K] weight streams through LDS.
-// ------------------------------------------------------------------------------------------------
-constexpr int RBM = 64, RBN = 256;
-constexpr int RT_PITCH = 260;                      // fp32 epilogue image pitch (floats)
-constexpr int ROW_LDS_BYTES = 40960;               // 8 KiB A + 32 KiB W staging; the epilogue image is [32][260] fp32 = 33280 B
-
-template <typename T>
-struct GemmRow {
-  GemmNT<T> g;
-  int ln_mode;
-  const float* gamma; const float* beta;
-  const T* ln_x; float* stats; T* ln_out; T* ln_out2; float* partial;
-  DropCfg l1, l2;
-};
-
-// 8 consecutive elements held raw (16 B for 16-bit types, 32 B for fp32) so loads can be issued long before their use
-template <typename T> struct Raw8;
-template <> struct Raw8<bf16_t> { u32x4 a; };
-template <> struct Raw8<f16_t> { u32x4 a; };
-template <> struct Raw8<float> { f32x4 a, b; };
-__device__ __forceinline__ Raw8<bf16_t> ldraw8(const bf16_t* p) { Raw8<bf16_t> r; r.a = *(const u32x4*)p; return r; }
-__device__ __forceinline__ Raw8<f16_t> ldraw8(const f16_t* p) { Raw8<f16_t> r; r.a = *(const u32x4*)p; return r; }
-__device__ __forceinline__ Raw8<float> ldraw8(const float* p) { Raw8<float> r; r.a = *(const f32x4*)p; r.b = *(const f32x4*)(p + 4); return r; }
-__device__ __forceinline__ void cvt8(const Raw8<bf16_t>& r, float v[8]) { load8((const bf16_t*)&r.a, v); }
-__device__ __forceinline__ void cvt8(const Raw8<f16_t>& r, float v[8]) { load8((const f16_t*)&r.a, v); }
-__device__ __forceinline__ void cvt8(const Raw8<float>& r, float v[8]) {
-  v[0] = r.a[0]; v[1] = r.a[1]; v[2] = r.a[2]; v[3] = r.a[3]; v[4] = r.b[0]; v[5] = r.b[1]; v[6] = r.b[2]; v[7] = r.b[3];
-}
-
-__device__ __forceinline__ float half_sum32(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
-template <typename T, int LN>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void gemm_nt_row_kernel(GemmRow<T> q) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const GemmNT<T>& p = q.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bid = xcd_remap(blockIdx.x, p.nblocks);
-  const int m0 = bid * RBM;
-
-  const int crow = tid >> 3, cch = tid & 7;
-  const char* ap[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) ap[i] = (const char*)(p.A + row_off(p.a, min(m0 + crow + 32 * i, p.M - 1))) + cch * 16;
-  // the eight weight rows of a thread differ by a wave-uniform stride: one 32-bit lane offset + scalar bases
-  const char* const wbase = (const char*)p.W;
-  const uint32_t woff = (uint32_t)crow * (uint32_t)p.ldw * (uint32_t)sizeof(T) + (uint32_t)cch * 16u;
-  const size_t wstep = (size_t)32 * (size_t)p.ldw * sizeof(T);
-  const int soff = crow * 128 + ((cch ^ (crow & 7)) << 4);
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.K / (128 / (int)sizeof(T));
-  u32x4 ra[2], rw[8];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) ra[i] = *(const u32x4*)(ap[i]);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) rw[i] = *(const u32x4*)(wbase + i * wstep + woff);
-  for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) *(u32x4*)(smem + soff + i * 4096) = ra[i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *(u32x4*)(smem + 8192 + soff + i * 4096) = rw[i];
-    __syncthreads();
-    if (kt + 1 < nk) {
-      const size_t ko = (size_t)(kt + 1) * 128;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) ra[i] = *(const u32x4*)(ap[i] + ko);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) rw[i] = *(const u32x4*)(wbase + (i * wstep + ko) + woff);
-    }
-    mma_ktile<T>(smem, smem + 8192, 0, wave, lane, acc);
-    __syncthreads();
-  }
-
-  // ---- epilogue: two passes of 32 rows through a [32][260] fp32 LDS image (fits the 40 KiB staging allocation, so three
-  //      workgroups share a CU); a half-wave (32 lanes x 8 columns) owns a row, 4 rows per thread and pass ----
-  float* ct = (float*)smem;
-  const int ch = tid & 31, rg = tid >> 5, n = ch * 8;
-  uint32_t seed_lo = 0, seed_hi = 0;
-  if (p.d1.thresh | p.d2.thresh | q.l1.thresh | q.l2.thresh) {
-    seed_lo = p.st->seed_lo;
-    seed_hi = p.st->seed_hi;
-  }
-  float bv[8], gam[8], bet[8], pg[8], pb[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { bv[j] = 0.f; gam[j] = 1.f; bet[j] = 0.f; pg[j] = 0.f; pb[j] = 0.f; }
-  if (p.bias) load8(p.bias + n, bv);
-  if (LN) load8(q.gamma + n, gam);
-  if (LN == 1) load8(q.beta + n, bet);
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    // the HBM operands of this pass are requested before the LDS transposition so that their latency hides under it
-    Raw8<T> res_raw[4], x_raw[4];
-    float st_mean[4], st_rstd[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int mc = min(m0 + half * 32 + rg + 8 * i, p.M - 1);
-      if (p.residual) res_raw[i] = ldraw8(p.residual + row_off(p.r, mc) + n);
-      if (LN == 2) {
-        x_raw[i] = ldraw8(q.ln_x + (long long)mc * RBN + n);
-        st_mean[i] = q.stats[2 * (long long)mc];
-        st_rstd[i] = q.stats[2 * (long long)mc + 1];
-      }
-    }
-    {
-      const int l15 = lane & 15, g = lane >> 4;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-          *(f32x4*)(ct + (mh * 16 + l15) * RT_PITCH + wave * 64 + ni * 16 + 4 * g) = acc[ni][half * 2 + mh];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = rg + 8 * i;
-      const int m = m0 + half * 32 + row;
-      const bool ok = m < p.M;            // uniform over the half-wave that owns the row
-      const int mc = ok ? m : p.M - 1;
-      float v[8];
-      load8(ct + row * RT_PITCH + n, v);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + bv[j], p.act);
-      const long long coff = row_off(p.c, mc) + n;
-      if (p.gate) {
-        float gv[8];
-        load8(p.gate + coff, gv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gv[j] > 0.f ? v[j] * p.gate_scale : 0.f;
-      }
-      const uint32_t idx = (uint32_t)mc * (uint32_t)RBN + (uint32_t)n;
-      if (p.d1.thresh | p.d2.thresh) {
-        eg_dropout_run<8>(v, p.d1, seed_lo, seed_hi, idx);
-        eg_dropout_run<8>(v, p.d2, seed_lo, seed_hi, idx);
-      }
-      if (p.out_pre && ok) store8(p.out_pre + row_off(p.pm, mc) + n, v);
-      if (p.residual) {
-        float rv[8];
-        cvt8(res_raw[i], rv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += rv[j];
-      }
-      if (p.C && ok) store8(p.C + coff, v);
-      if (LN == 1) {
-        if (sizeof(T) == 2) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = round_store<T>(v[j]);   // normalise exactly what was stored
-        }
-        float s1 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s1 += v[j];
-        const float mean = half_sum32(s1) * (1.0f / 256.f);
-        float s2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float dlt = v[j] - mean; s2 += dlt * dlt; }
-        const float rstd = rsqrtf(half_sum32(s2) * (1.0f / 256.f) + 1e-5f);
-        if (ok) {
-          float y[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) y[j] = (v[j] - mean) * rstd * gam[j] + bet[j];
-          store8(q.ln_out + (long long)m * RBN + n, y);
-          if (ch == 0) {
-            q.stats[2 * (long long)m] = mean;
-            q.stats[2 * (long long)m + 1] = rstd;
-          }
-        }
-      } else if (LN == 2) {
-        float xv[8];
-        cvt8(x_raw[i], xv);
-        const float mean = st_mean[i], rstd = st_rstd[i];
-        float xh[8], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          xh[j] = (xv[j] - mean) * rstd;
-          const float gy = v[j] * gam[j];
-          s1 += gy;
-          s2 += gy * xh[j];
-        }
-        const float c1 = half_sum32(s1) * (1.0f / 256.f), c2 = half_sum32(s2) * (1.0f / 256.f);
-        if (ok) {
-          float o[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            pg[j] += v[j] * xh[j];
-            pb[j] += v[j];
-            o[j] = rstd * (v[j] * gam[j] - c1 - xh[j] * c2);
-          }
-          store8(q.ln_out + (long long)m * RBN + n, o);
-          if (q.ln_out2) {
-            eg_dropout_run<8>(o, q.l1, seed_lo, seed_hi, idx);
-            eg_dropout_run<8>(o, q.l2, seed_lo, seed_hi, idx);
-            store8(q.ln_out2 + (long long)m * RBN + n, o);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (LN == 2) {
-    // gain / bias partials of this block's 64 rows: 8 row groups -> one [2][256] slab, fixed order (deterministic)
-    float* red = (float*)smem;   // [8][2][256]
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      red[(rg * 2 + 0) * 256 + n + j] = pg[j];
-      red[(rg * 2 + 1) * 256 + n + j] = pb[j];
-    }
-    __syncthreads();
-    for (int i = tid; i < 512; i += 256) {
-      float sacc = 0.f;
-#pragma unroll
-      for (int h = 0; h < 8; ++h) sacc += red[h * 512 + i];
-      q.partial[(size_t)bid * 512 + i] = sacc;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // TN (weight gradient).  LDS tiles hold [32 reduction rows][128 columns]; bf16 fragments are gathered
 // with ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, delivered column-major).
 // chunk swizzle f(r) = 2*((r&3) | ((r>>1)&4)): the 8 rows one half-wave touches land on 8 distinct
@@ -1029,60 +797,24 @@ static int launch_gemm_nt(const eg_gemm_desc* d, hipStream_t s) {
   return 0;
 }
 
-template <typename T>
-static void fill_gemm_nt(GemmNT<T>& p, const eg_gemm_desc* d) {
-  p.A = (const T*)d->A; p.W = (const T*)d->W; p.C = (T*)d->C; p.bias = d->bias;
-  p.residual = (const T*)d->residual; p.gate = (const T*)d->gate; p.out_pre = (T*)d->out_pre; p.st = d->state;
-  p.a = to_rowmap(d->a); p.c = to_rowmap(d->c); p.r = to_rowmap(d->r); p.pm = to_rowmap(d->p);
-  p.M = d->M; p.N = d->N; p.K = d->K; p.ldw = d->ldw; p.act = d->act;
-  p.d1 = make_drop(d->drop1_p, d->drop1_site);
-  p.d2 = make_drop(d->drop2_p, d->drop2_site);
-  p.gate_scale = d->gate_scale == 0.f ? 1.0f : d->gate_scale;
-  p.seg_tiles = 0;
-  p.seg_stride_bytes = 0;
-}
-
-template <typename T>
-static int launch_gemm_row(const eg_gemm_desc* d, hipStream_t s) {
-  GemmRow<T> q;
-  fill_gemm_nt<T>(q.g, d);
-  q.g.tiles_n = 1;
-  q.g.nblocks = (d->M + RBM - 1) / RBM;
-  q.ln_mode = d->ln_mode;
-  q.gamma = d->ln_gamma; q.beta = d->ln_beta; q.ln_x = (const T*)d->ln_x; q.stats = d->ln_stats;
-  q.ln_out = (T*)d->ln_out; q.ln_out2 = (T*)d->ln_out2; q.partial = d->ln_partial;
-  q.l1 = make_drop(d->ln_drop1_p, d->ln_drop1_site);
-  q.l2 = make_drop(d->ln_drop2_p, d->ln_drop2_site);
-  const dim3 grid(q.g.nblocks), blk(256);   // 40 KiB dynamic LDS: below the 64 KiB default limit, no attribute needed
-  if (d->ln_mode == 1) hipLaunchKernelGGL((gemm_nt_row_kernel<T, 1>), grid, blk, ROW_LDS_BYTES, s, q);
-  else if (d->ln_mode == 2) hipLaunchKernelGGL((gemm_nt_row_kernel<T, 2>), grid, blk, ROW_LDS_BYTES, s, q);
-  else hipLaunchKernelGGL((gemm_nt_row_kernel<T, 0>), grid, blk, ROW_LDS_BYTES, s, q);
-  EG_LAUNCH_CHECK("gemm_nt_row");
-  return 0;
-}
-
 int eg_rs_gemm_try(const eg_gemm_desc* d, hipStream_t s);   // rsgemm.hip: register-stationary row-stream kernel (K == 256)
 int eg_wide_gemm_try(const eg_gemm_desc* d, hipStream_t s); // widegemm.hip: 160x256 tile, LDS-DMA ring (N == 256)
 
 bool eg_rs_gemm_ok(const eg_gemm_desc* d);
 bool eg_wide_gemm_ok(const eg_gemm_desc* d);
-bool eg_tall_gemm_ok(const eg_gemm_desc* d);                 // tallgemm.hip: one wave per SIMD, weights in fragment order
-int eg_tall_gemm_try(const eg_gemm_desc* d, hipStream_t s);
 static int gemm_knob(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 1; }
 
 // which kernel eg_gemm_nt launches for this descriptor (measurement aid: bench.py attributes its per-launch timings with it)
 extern "C" int eg_gemm_nt_route(const eg_gemm_desc* d) {
   if (!d) return -1;
-  static const int use_rs = gemm_knob("EYEGAZE_RS"), use_wide = gemm_knob("EYEGAZE_WIDE"), use_tall = gemm_knob("EYEGAZE_TALL");
-  if (use_tall && eg_tall_gemm_ok(d)) return EG_ROUTE_TALL;
+  static const int use_rs = gemm_knob("EYEGAZE_RS"), use_wide = gemm_knob("EYEGAZE_WIDE");
   if (use_wide && eg_wide_gemm_ok(d)) return EG_ROUTE_WIDE;
   if (use_rs && eg_rs_gemm_ok(d)) return EG_ROUTE_ROWSTREAM;
-  if (d->ln_mode != 0 || d->row_tile) return EG_ROUTE_ROWTILE;
   return EG_ROUTE_TILED;
 }
 
 extern "C" int eg_gemm_nt(const eg_gemm_desc* d, void* stream) {
-  EG_CHECK(d && d->A && d->W && (d->C || d->ln_mode == 2), "eg_gemm_nt: null operand");
+  EG_CHECK(d && d->A && d->W && d->C, "eg_gemm_nt: null operand");
   EG_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "eg_gemm_nt: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
   EG_CHECK(d->dtype == EG_F32 || d->dtype == EG_BF16 || d->dtype == EG_F16, "eg_gemm_nt: bad dtype %d", d->dtype);
   const int bk = d->dtype == EG_F32 ? 32 : 64;
@@ -1101,12 +833,7 @@ extern "C" int eg_gemm_nt(const eg_gemm_desc* d, void* stream) {
   EG_CHECK((long long)d->M * d->N < (1ll << 32), "eg_gemm_nt: M*N exceeds the 32-bit dropout index");
   EG_CHECK(((uintptr_t)d->A | (uintptr_t)d->W | (uintptr_t)d->C) % 16 == 0, "eg_gemm_nt: operands must be 16-B aligned");
   hipStream_t s = (hipStream_t)stream;
-  static const int use_rs = gemm_knob("EYEGAZE_RS"), use_wide = gemm_knob("EYEGAZE_WIDE"), use_tall = gemm_knob("EYEGAZE_TALL");
-  if (use_tall) {                                  // N == 256, deep K, fragment-ordered weights at hand
-    const int rc = eg_tall_gemm_try(d, s);
-    if (rc == 0) return 0;
-    if (rc != -1) return eg_fail("tall gemm launch failed");
-  }
+  static const int use_rs = gemm_knob("EYEGAZE_RS"), use_wide = gemm_knob("EYEGAZE_WIDE");
   if (use_wide) {                                  // N == 256 (any K): one workgroup per 160 whole rows
     const int rc = eg_wide_gemm_try(d, s);
     if (rc == 0) return 0;
@@ -1116,19 +843,6 @@ extern "C" int eg_gemm_nt(const eg_gemm_desc* d, void* stream) {
     const int rc = eg_rs_gemm_try(d, s);
     if (rc == 0) return 0;
     if (rc != -1) return eg_fail("rs_gemm launch failed");
-  }
-  if (d->ln_mode != 0 || d->row_tile) {
-    EG_CHECK(d->ln_mode >= 0 && d->ln_mode <= 2, "eg_gemm_nt: ln_mode %d", d->ln_mode);
-    EG_CHECK(d->N == RBN, "eg_gemm_nt: the row-complete tile (LayerNorm epilogue) needs N == %d, got %d", RBN, d->N);
-    EG_CHECK(d->a_seg_len == 0, "eg_gemm_nt: segmented A rows are not supported by the row-complete tile");
-    if (d->ln_mode == 1)
-      EG_CHECK(d->C && d->ln_gamma && d->ln_beta && d->ln_out && d->ln_stats, "eg_gemm_nt: ln_mode 1 needs C, gamma, beta, ln_out, ln_stats");
-    if (d->ln_mode == 2) {
-      EG_CHECK(d->ln_gamma && d->ln_x && d->ln_stats && d->ln_out && d->ln_partial, "eg_gemm_nt: ln_mode 2 needs gamma, ln_x, ln_stats, ln_out, ln_partial");
-      EG_CHECK((d->ln_drop1_p == 0.f && d->ln_drop2_p == 0.f) || (d->state && d->ln_out2), "eg_gemm_nt: ln dropout needs a step state and ln_out2");
-      EG_CHECK(d->ln_drop1_p >= 0.f && d->ln_drop1_p < 1.f && d->ln_drop2_p >= 0.f && d->ln_drop2_p < 1.f, "eg_gemm_nt: ln dropout p");
-    }
-    return d->dtype == EG_BF16 ? launch_gemm_row<bf16_t>(d, s) : d->dtype == EG_F16 ? launch_gemm_row<f16_t>(d, s) : launch_gemm_row<float>(d, s);
   }
   return d->dtype == EG_BF16 ? launch_gemm_nt<bf16_t>(d, s) : d->dtype == EG_F16 ? launch_gemm_nt<f16_t>(d, s) : launch_gemm_nt<float>(d, s);
 }

@@ -344,7 +344,7 @@ static int rs_gemm_launch(const eg_gemm_desc* d, hipStream_t s, int cus) {
 bool eg_rs_gemm_ok(const eg_gemm_desc* d) {
   if ((d->dtype != EG_BF16 && d->dtype != EG_F16) || d->K != 256 || d->N % 256 != 0 || d->ldw != 256) return false;
   if (d->a.rows_per_group || d->c.rows_per_group || d->r.rows_per_group || d->p.rows_per_group) return false;
-  if (d->a_seg_len || d->ln_mode || d->row_tile || d->act == EG_ACT_GELU) return false;
+  if (d->a_seg_len || d->act == EG_ACT_GELU) return false;
   if (d->residual && d->gate) return false;
   if (!d->C) return false;
   if (d->a.row_stride % 8 || d->c.row_stride % 8 || (d->residual && d->r.row_stride % 8) || (d->out_pre && d->p.row_stride % 8)) return false;

@@ -227,7 +227,7 @@ static int wide_launch(const eg_gemm_desc* d, hipStream_t s) {
 // eligibility + launch; returns -1 when the product does not fit this kernel (caller falls back)
 bool eg_wide_gemm_ok(const eg_gemm_desc* d) {
   if ((d->dtype != EG_BF16 && d->dtype != EG_F16) || d->N != WBN || d->K % 64 != 0 || d->K < 128) return false;
-  if (d->a_seg_len || d->ln_mode || d->row_tile || !d->C) return false;
+  if (d->a_seg_len || !d->C) return false;
   if (d->M < 1024) return false;               // the head products (M = batch) keep the 128x128 tile
   // the epilogue reads residual / gate rows and writes out_pre rows as 16-B vectors: misaligned bases keep the 128x128 tile
   if (((uintptr_t)d->residual | (uintptr_t)d->gate | (uintptr_t)d->out_pre | (uintptr_t)d->C | (uintptr_t)d->A | (uintptr_t)d->W) % 16)

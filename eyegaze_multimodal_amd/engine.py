@@ -154,21 +154,12 @@ class Engine:
         self.fp: FlatParams = model._flat
         self.stream = 0
         self.probes = {}   # tag -> (start_event, end_event) recorded around that launch
-        # LayerNorm forward / backward run in the epilogue of the adjacent N == d_model product (row-complete GEMM tile)
-        self.fuse_ln = cfg.d_model == 256 and os.environ.get("EYEGAZE_FUSE_LN", "0") == "1"
-        # norm2 in the FFN chain's epilogue (the workgroup owns whole rows): parity-tested, measured EQUAL to the stand-alone
-        # LayerNorm launch (3.795 vs 3.790 ms / step: the epilogue's extra 17 MB store and three barriers cost what the 8.5 us
-        # launch cost), so opt-in
-        self.ffn_ln = os.environ.get("EYEGAZE_FFN_LN", "0") == "1"
-        # q|k|v through eg_ffn_chain's product-1-only form: bit-identical, measured EQUAL to the row-stream GEMM (29 vs 28 us per
-        # launch, step 3.716 vs 3.703 ms), so opt-in
-        self.qkv_chain = os.environ.get("EYEGAZE_QKV_CHAIN", "0") == "1"
         self.cus = torch.cuda.get_device_properties(device).multi_processor_count if device.type == "cuda" else 256
         # attention half of an encoder layer (q|k|v projection, attention core, out-proj + dropout + residual) as ONE launch with a
         # workgroup per window (csrc/attnblock.hip): 16-bit compute dtypes, d_model == 256, 8 heads, S <= 80 (set after S is known)
         self.attn_block = False
         # feed-forward pair as one launch (csrc/ffn.hip): 16-bit compute dtypes, d_model == 256, d_ff a multiple of 128
-        self.fuse_ffn = (dtype != EG_F32 and cfg.d_model == 256 and cfg.d_ff % 128 == 0 and not self.fuse_ln
+        self.fuse_ffn = (dtype != EG_F32 and cfg.d_model == 256 and cfg.d_ff % 128 == 0
                          and os.environ.get("EYEGAZE_FFN", "1") != "0")
         # LayerNorm backward: a block walks 8 rows per trip; about a thousand blocks (4 waves per SIMD) whose trip count divides M
         # evenly -- 33 280 rows: 1040 blocks x 4 trips, against 512 blocks x 8.1 -> 9 trips (measured 3.90 -> 3.87 ms / step)
@@ -180,10 +171,8 @@ class Engine:
             raise L.EgError(f"EYEGAZE_LN_BLOCKS={env_nb} is outside [1, {self.LN_PARTIAL_BLOCKS}] (rows of the LayerNorm-backward "
                             "partial buffer)")
         self.ln_nblk_cap = max(self.LN_BLOCKS, (self.M + 63) // 64)
-        if (self.M + 63) // 64 > 2048:
-            self.fuse_ln = False      # the scratch partial buffer holds 2048 workgroups
         self.probe_all = None  # list of (start, end, flops) for every gemm_nt launch when bench.py enables it
-        self.attn_block = bool(self._want_attn_block and dtype != EG_F32 and not self.fuse_ln
+        self.attn_block = bool(self._want_attn_block and dtype != EG_F32
                                and L.lib().eg_attn_block_ok(self.S, cfg.d_model, cfg.num_heads, dtype))
         self._alloc()
         self.packed_version = -1
@@ -203,13 +192,6 @@ class Engine:
         w["conv0"] = self._t(d, self.K0)
         w["conv1"] = self._t(d, self.k * d)
         w["conv1T"] = self._t(self.s, d, self.J * d)
-        # the same two in MFMA-fragment order for the tall (one wave per SIMD) tile: N == 256, K a multiple of 256, 16-bit
-        # (measured no faster than the wide tile -- csrc/tallgemm.hip -- so opt-in)
-        self.tall_conv = (self.dtype != EG_F32 and d == 256 and (self.k * d) % 256 == 0 and (self.J * d) % 256 == 0
-                          and os.environ.get("EYEGAZE_TALL_CONV", "0") == "1")
-        if self.tall_conv:
-            w["conv1f"] = self._t(d * self.k * d)
-            w["conv1Tf"] = self._t(self.s * d * self.J * d)
         w["pos"] = self._t(cfg.max_len, d)
         for l in list(range(L_)) + (["x"] if cfg.use_cross_attention else []):
             w[f"qkv{l}"] = self._t(3 * d, d)
@@ -217,8 +199,6 @@ class Engine:
             w[f"o{l}"] = self._t(d, d)
             w[f"oT{l}"] = self._t(d, d)
             w[f"bqkv{l}"] = self._t(3 * d, dtype=f32)
-            if self.fuse_ffn and self.qkv_chain:      # q|k|v weights in eg_ffn_chain's fragment order (product-1-only form)
-                w[f"qkvf{l}"] = self._t(3 * d * d)
             if self.attn_block and l != "x":          # eg_attn_block_fwd's fragment-ordered q|k|v and out-proj weights
                 w[f"wqkvb{l}"] = self._t(3 * d * d)
                 w[f"wob{l}"] = self._t(d * d)
@@ -374,17 +354,14 @@ class Engine:
     # thin wrappers
     # ------------------------------------------------------------------------------------------
     def gemm(self, A, W, Cout, M, N, K, *, a=None, c=None, r=None, p=None, ldw=None, bias=0, residual=0, gate=0,
-             out_pre=0, act=0, drop1=(0.0, 0), drop2=(0.0, 0), gate_scale=1.0, tag=None, seg=(0, 0), ln=None, w_frag=0):
-        """ln: LayerNorm fused into the epilogue of an N == 256 product (eg_gemm_desc.ln_*):
-        dict(mode=1, gamma, beta, out, stats) or dict(mode=2, gamma, x, stats, out, out2, partial, d1, d2)."""
+             out_pre=0, act=0, drop1=(0.0, 0), drop2=(0.0, 0), gate_scale=1.0, tag=None, seg=(0, 0)):
         probe = self.probes.get(tag) if tag else None
         dsc = self._gemm_desc(A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2,
-                              gate_scale, seg, ln)
-        dsc.W_frag = w_frag or None
+                              gate_scale, seg)
         if self.probe_all is not None:      # bench.py: HIP events around EVERY eg_gemm_nt launch of the timed region
             probe = self._probe_pair()
             self.probe_all.append((probe[0], probe[1], 2.0 * M * N * K,
-                                   self._gemm_bytes(M, N, K, a, seg, residual, gate, out_pre, ln, Cout), (M, N, K),
+                                   self._gemm_bytes(M, N, K, a, seg, residual, gate, out_pre, Cout), (M, N, K),
                                    L.lib().eg_gemm_nt_route(C.byref(dsc))))
         if probe:
             probe[0].record(torch.cuda.current_stream(self.device))
@@ -393,13 +370,9 @@ class Engine:
             probe[1].record(torch.cuda.current_stream(self.device))
 
     def qkv_proj(self, x, l):
-        """q|k|v = x W^T + b (A:203-205), fused over the three projections: eg_ffn_chain's product-1-only form (the A tile resident
-        in LDS, fragment-ordered weights straight to registers) when available, else the row-stream GEMM"""
+        """q|k|v = x W^T + b (A:203-205), fused over the three projections (the row-stream GEMM at K = 256)"""
         M, d = self.M, self.cfg.d_model
-        if self.fuse_ffn and self.qkv_chain:
-            self.ffn(ptr(x), ptr(self.w[f"qkvf{l}"]), 0, ptr(self.a[f"qkv{l}"]), 0, M, 3 * d, bias1=ptr(self.w[f"bqkv{l}"]))
-        else:
-            self.gemm(ptr(x), ptr(self.w[f"qkv{l}"]), ptr(self.a[f"qkv{l}"]), M, 3 * d, d, bias=ptr(self.w[f"bqkv{l}"]))
+        self.gemm(ptr(x), ptr(self.w[f"qkv{l}"]), ptr(self.a[f"qkv{l}"]), M, 3 * d, d, bias=ptr(self.w[f"bqkv{l}"]))
 
     def attn_block_fwd(self, x, l, p, sites):
         """eg_attn_block_fwd (csrc/attnblock.hip): A:202-213 + the residual of A:292-293 for encoder layer l in one launch"""
@@ -433,11 +406,11 @@ class Engine:
         return (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
     def ffn(self, A, W1f, W2f, H, Cout, M, F, *, bias1=0, bias2=0, act1=0, residual=0, gate=0, bits_out=0, bits_in=0,
-            drop_h=(0.0, 0), drop_c1=(0.0, 0), drop_c2=(0.0, 0), gate_scale=1.0, ln=None):
+            drop_h=(0.0, 0), drop_c1=(0.0, 0), drop_c2=(0.0, 0), gate_scale=1.0):
         """eg_ffn_chain: H = epi1(A W1^T), C = epi2(H W2^T) in one launch (weights in fragment order)."""
         d = self.cfg.d_model
         dsc = L.FfnDesc()
-        dsc.A, dsc.W1, dsc.W2, dsc.H, dsc.C = A, W1f, W2f or None, H, Cout or None
+        dsc.A, dsc.W1, dsc.W2, dsc.H, dsc.C = A, W1f, W2f, H, Cout
         dsc.bias1, dsc.bias2, dsc.gate, dsc.residual = bias1 or None, bias2 or None, gate or None, residual or None
         dsc.gate_bits_out, dsc.gate_bits_in = bits_out or None, bits_in or None
         dsc.state = self.st_ptr
@@ -447,17 +420,13 @@ class Engine:
         dsc.drop_c1_p, dsc.drop_c1_site = drop_c1
         dsc.drop_c2_p, dsc.drop_c2_site = drop_c2
         dsc.gate_scale = gate_scale
-        if ln:                              # (gamma, beta, out, stats): the LayerNorm that follows the block, in the same launch
-            dsc.ln_gamma, dsc.ln_beta, dsc.ln_out, dsc.ln_stats = ln
         probe = None
         if self.probe_all is not None:      # bench.py: timed like the eg_gemm_nt launches, as its own kernel (route 4)
             probe = self._probe_pair()
             es = self.es
-            nbytes = es * (M * d * (2 + (1 if residual and residual != A else 0) + (1 if ln else 0)) + M * F * (1 + (1 if gate else 0)) + 2 * F * d) \
+            nbytes = es * (M * d * (2 + (1 if residual and residual != A else 0)) + M * F * (1 + (1 if gate else 0)) + 2 * F * d) \
                 + (M * F // 8 if (bits_out or bits_in) else 0) + 4 * (F + d)
-            if not W2f:                     # product-1-only form: one K = d product
-                nbytes = es * (M * d + M * F + F * d) + 4 * F
-            self.probe_all.append((probe[0], probe[1], (4.0 if W2f else 2.0) * M * F * d, float(nbytes), (M, F, d), 4 if W2f else 7))
+            self.probe_all.append((probe[0], probe[1], 4.0 * M * F * d, float(nbytes), (M, F, d), 4))
             probe[0].record(torch.cuda.current_stream(self.device))
         call("eg_ffn_chain", C.byref(dsc), self.stream)
         if probe:
@@ -480,7 +449,7 @@ class Engine:
         finally:
             drop_module.training = was
 
-    def _gemm_bytes(self, M, N, K, a, seg, residual, gate, out_pre, ln=None, Cout=1) -> float:
+    def _gemm_bytes(self, M, N, K, a, seg, residual, gate, out_pre, Cout=1) -> float:
         """Algorithmic HBM bytes of one gemm_nt launch: every distinct operand element read once, every output element
         written once (overlapping conv rows count once; the weights count once)."""
         es = self.es
@@ -493,22 +462,11 @@ class Engine:
             a_elems = M * K
         outs = (1 if Cout else 0) + (1 if out_pre else 0)
         ins = (1 if residual else 0) + (1 if gate else 0)
-        if ln:      # fused LayerNorm: its output row(s), and in backward the saved input row
-            outs += 1 + (1 if ln.get("out2") else 0)
-            ins += 1 if ln["mode"] == 2 else 0
         return float(es * (a_elems + N * K + (outs + ins) * M * N) + 4 * N)
 
     def _gemm_desc(self, A, W, Cout, M, N, K, a, c, r, p, ldw, bias, residual, gate, out_pre, act, drop1, drop2, gate_scale,
-                   seg=(0, 0), ln=None):
+                   seg=(0, 0)):
         dsc = GemmDesc()
-        if ln:
-            dsc.ln_mode, dsc.ln_gamma, dsc.ln_stats, dsc.ln_out = ln["mode"], ln["gamma"], ln["stats"], ln["out"]
-            if ln["mode"] == 1:
-                dsc.ln_beta = ln["beta"]
-            else:
-                dsc.ln_x, dsc.ln_out2, dsc.ln_partial = ln["x"], ln.get("out2") or None, ln["partial"]
-                dsc.ln_drop1_p, dsc.ln_drop1_site = ln.get("d1", (0.0, 0))
-                dsc.ln_drop2_p, dsc.ln_drop2_site = ln.get("d2", (0.0, 0))
         dsc.a_seg_len, dsc.a_seg_stride = seg
         dsc.A, dsc.W, dsc.C = A, W, Cout or None
         dsc.bias, dsc.residual, dsc.gate, dsc.out_pre = bias or None, residual or None, gate or None, out_pre or None
@@ -684,78 +642,27 @@ class Engine:
             for k, (i, n) in enumerate(lns):   # deferred LayerNorm gain / bias partials ride in the same reduce launch
                 r = rt[len(sel) + k]
                 r.partial, r.out = ptr(g["lnpart_all"]) + 4 * i * self.ln_nblk_cap * 2 * d, fp.g_ptr(n + ".weight")
-                # LayerNorms whose backward runs in a GEMM epilogue leave one partial per 64-row workgroup; the top layer's ln2
-                # keeps the stand-alone kernel (its input gradient comes from encoder.norm, not from a product)
-                fused = self.fuse_ln and not n.endswith(f"layers.{cfg.num_layers - 1}.ln2")
-                r.n, r.stride, r.splits, r.blk0 = 2 * d, 2 * d, ((M + 63) // 64 if fused else self.LN_BLOCKS), rblk
+                r.n, r.stride, r.splits, r.blk0 = 2 * d, 2 * d, self.LN_BLOCKS, rblk
                 rblk += _reduce_blocks(2 * d, r.splits)
             return dict(tp=dev(tp), rt=dev(rt), n=len(sel), nr=len(sel) + len(lns), blocks=blk, rblocks=rblk, layers=list(layers),
                         splits=nsplit)
 
         Lr = cfg.num_layers
         whole = tables(range(Lr), with_cross=True)
-        # the same problems as per-layer tables: used when the weight gradients of a layer are launched on the side stream as
-        # soon as that layer's backward-data chain has produced them (EYEGAZE_WGRAD_OVERLAP=1)
-        per_layer = []
-        for l in range(Lr):
-            t1 = tables([l])
-            per_layer.append((t1["tp"], t1["blocks"]))
         # data parallel: two pieces, so the gradient buckets of layers L-1 .. L/2 start their all-reduce while layers L/2-1 .. 0
         # are still in backward (one piece would hold every encoder bucket back until backward has finished)
         h = Lr // 2
         pieces = ([tables(range(h, Lr), with_cross=True, nsplit=splits_p), tables(range(0, h), nsplit=splits_p)]
                   if Lr >= 2 else [whole])
-        cross_only = tables([], with_cross=True) if ncross else None      # (side-stream mode: the cross block's pair on its own)
-        self._wg_plan = dict(whole, splits=splits, per_layer=per_layer, pieces=pieces, split_layer=h, cross_only=cross_only,
+        self._wg_plan = dict(whole, splits=splits, pieces=pieces, split_layer=h,
                              entry="eg_gemm_tn_grouped256" if big else "eg_gemm_tn_grouped")
         return self._wg_plan
 
     def _wgrad_group_launch(self, piece=None):
         """piece: None = every encoder layer in one launch; else one of `_wg_plan['pieces']` (data-parallel runs)."""
         pl = self._wg_plan if piece is None else piece
-        if self._wg_side is not None:          # the per-layer launches are already queued on the side stream: join it
-            torch.cuda.current_stream(self.device).wait_stream(self._wg_side)
-            co = self._wg_plan.get("cross_only")
-            if co is not None:
-                call(self._wg_plan["entry"], ptr(co["tp"]), co["n"], co["blocks"], self.M, self._wg_plan["splits"], self.dtype, self.stream)
-        else:
-            call(self._wg_plan["entry"], ptr(pl["tp"]), pl["n"], pl["blocks"], self.M, pl["splits"], self.dtype, self.stream)
+        call(self._wg_plan["entry"], ptr(pl["tp"]), pl["n"], pl["blocks"], self.M, pl["splits"], self.dtype, self.stream)
         call("eg_reduce_table", ptr(pl["rt"]), pl["nr"], pl["rblocks"], self.stream)
-
-    def _wgrad_layer_async(self, l: int):
-        """Weight gradients of encoder layer l on the side stream, behind an event recorded after the layer's backward-data
-        chain: they are independent of everything the main stream does until the final reduce, and the latency-bound K = 256
-        products of the lower layers leave room for them (EYEGAZE_WGRAD_OVERLAP=1)."""
-        tab, nblk = self._wg_plan["per_layer"][l]
-        cur = torch.cuda.current_stream(self.device)
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        self._wg_side.wait_event(ev)
-        call(self._wg_plan["entry"], ptr(tab), 4, nblk, self.M, self._wg_plan["splits"], self.dtype, self._wg_side.cuda_stream)
-
-    def _ln_f(self, gname, y, stats):
-        """forward LayerNorm spec for gemm(ln=...) — None when the fused epilogue is unavailable (d_model != 256)"""
-        if not self.fuse_ln:
-            return None
-        return dict(mode=1, gamma=self.fp.p_ptr(gname + ".weight"), beta=self.fp.p_ptr(gname + ".bias"), out=ptr(y), stats=ptr(stats))
-
-    def _ln_b(self, gname, x, stats, dx, dx_drop, d1=(0.0, 0), d2=(0.0, 0), slot=None):
-        """backward LayerNorm spec for gemm(ln=...); the per-workgroup gain/bias partials go to the slot's deferred buffer
-        (grouped reduce) or to the scratch buffer that `_ln_b_finish` reduces right after the product"""
-        d, nblk = self.cfg.d_model, (self.M + 63) // 64
-        lp = ptr(self.g["lnpart"]) if slot is None else ptr(self.g["lnpart_all"]) + 4 * slot * self.ln_nblk_cap * 2 * d
-        return dict(mode=2, gamma=self.fp.p_ptr(gname + ".weight"), x=ptr(x), stats=ptr(stats), out=ptr(dx),
-                    out2=ptr(dx_drop) if dx_drop is not None else 0, partial=lp, d1=d1, d2=d2, _name=gname, _slot=slot, _nblk=nblk)
-
-    def _ln_b_finish(self, spec):
-        if spec["_slot"] is not None:
-            return
-        d, gname, lp, nblk = self.cfg.d_model, spec["_name"], spec["partial"], spec["_nblk"]
-        if self.fp.offsets[gname + ".bias"] == self.fp.offsets[gname + ".weight"] + d:
-            call("eg_reduce_partials", lp, self.fp.g_ptr(gname + ".weight"), 2 * d, nblk, 2 * d, 0, self.stream)
-        else:
-            call("eg_reduce_partials", lp, self.fp.g_ptr(gname + ".weight"), d, nblk, 2 * d, 0, self.stream)
-            call("eg_reduce_partials", lp + 4 * d, self.fp.g_ptr(gname + ".bias"), d, nblk, 2 * d, 0, self.stream)
 
     def ln_fwd(self, x, gname, y, stats):
         call("eg_layernorm_fwd", ptr(x), self.fp.p_ptr(gname + ".weight"), self.fp.p_ptr(gname + ".bias"), ptr(y),
@@ -826,9 +733,6 @@ class Engine:
         call("eg_pack_conv_weight", fp.p_ptr("temporal_conv.convs.1.weight"), ptr(w["conv1"]), d, d, self.k, d, self.k * d,
              dt, st)
         call("eg_pack_convT_weight", fp.p_ptr("temporal_conv.convs.1.weight"), ptr(w["conv1T"]), d, d, self.k, self.s, dt, st)
-        if self.tall_conv:
-            call("eg_frag_order_rows", ptr(w["conv1"]), ptr(w["conv1f"]), self.k * d, self.k * d, 1, st)
-            call("eg_frag_order_rows", ptr(w["conv1T"]), ptr(w["conv1Tf"]), self.J * d, self.J * d, self.s, st)
         self.p_cast(fp.p_ptr("pos_embed.pos_embed.weight"), ptr(w["pos"]), cfg.max_len * d)
 
         def attn_pack(pre, l):
@@ -836,8 +740,6 @@ class Engine:
                 self.p_cast(fp.p_ptr(f"{pre}{n}.weight"), ptr(w[f"qkv{l}"]) + i * d * d * self.es, d * d)
                 self.p_transpose(fp.p_ptr(f"{pre}{n}.weight"), ptr(w[f"qkvT{l}"]) + i * d * self.es, d, d, 3 * d)
                 self.p_copy(fp.p_ptr(f"{pre}{n}.bias"), ptr(w[f"bqkv{l}"]) + 4 * i * d, d)
-                if self.fuse_ffn and self.qkv_chain:  # projection i = hidden chunks 2i, 2i+1 of the [768, 256] role-1 matrix
-                    self.p_frag(fp.p_ptr(f"{pre}{n}.weight"), ptr(w[f"qkvf{l}"]) + i * d * d * self.es, d, d, 3)
             self.p_cast(fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"o{l}"]), d * d)
             self.p_transpose(fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"oT{l}"]), d, d, d)
             if self.attn_block and l != "x":
@@ -893,8 +795,7 @@ class Engine:
         self.gemm(ptr(a["h0pad"]), ptr(w["conv1"]), ptr(a["x0"]) + self.off * d * es, NB * self.T2, d, self.k * d,
                   a=rowmap(self.s * d, self.R0 * d, self.T2), c=rowmap(d, S * d, self.T2),
                   r=rowmap(d, 0, self.T2), p=rowmap(d), bias=fp.p_ptr("temporal_conv.convs.1.bias"), act=L.ACT_RELU,
-                  drop1=(p01, SITE_CONV1), residual=ptr(w["pos"]) + self.off * d * es, out_pre=ptr(a["h1"]), tag="conv1_fwd",
-                  w_frag=ptr(w["conv1f"]) if self.tall_conv else 0)
+                  drop1=(p01, SITE_CONV1), residual=ptr(w["pos"]) + self.off * d * es, out_pre=ptr(a["h1"]), tag="conv1_fwd")
         # CLS rows (D:1157) + pos row 0
         call("eg_rows_bcast_f32", fp.p_ptr("cls_token"), fp.p_ptr("pos_embed.pos_embed.weight"), ptr(a["x0"]), NB, S, d, 1,
              0, 1, self.dtype, st)
@@ -912,24 +813,19 @@ class Engine:
                      sites["attn"], self.st_ptr, st)
                 self._probs_hook(self.model.encoder.layers[l].mha.dropout, a[f"qkv{l}"], a[f"lse{l}"], 0)
                 self.gemm(ptr(a[f"ctx{l}"]), ptr(w[f"o{l}"]), ptr(a[f"r1_{l}"]), M, d, d, bias=fp.p_ptr(pre + "mha.out_proj.bias"),
-                          drop1=(p, sites["drop1"]), residual=ptr(x), ln=self._ln_f(pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"]))
-            if not self.fuse_ln:
-                self.ln_fwd(a[f"r1_{l}"], pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"])
+                          drop1=(p, sites["drop1"]), residual=ptr(x))
+            self.ln_fwd(a[f"r1_{l}"], pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"])
             if self.fuse_ffn:       # linear1 -> ReLU -> dropout -> linear2 -> dropout x2 -> + residual in one launch (A:272, A:294)
                 self.ffn(ptr(a[f"y1_{l}"]), ptr(w[f"w1f{l}"]), ptr(w[f"w2f{l}"]), ptr(a[f"hff{l}"]), ptr(a[f"r2_{l}"]), M, F,
                          bias1=fp.p_ptr(pre + "ffn.linear1.bias"), bias2=fp.p_ptr(pre + "ffn.linear2.bias"), act1=L.ACT_RELU,
                          residual=ptr(a[f"y1_{l}"]), drop_h=(p, sites["ffn_a"]), drop_c1=(p, sites["ffn_b"]),
-                         drop_c2=(p, sites["drop2"]), bits_out=ptr(a[f"gbits{l}"]),
-                         ln=((fp.p_ptr(pre + "ln2.weight"), fp.p_ptr(pre + "ln2.bias"), ptr(a[f"x{l + 1}"]), ptr(a[f"st2_{l}"]))
-                             if self.ffn_ln else None))
+                         drop_c2=(p, sites["drop2"]), bits_out=ptr(a[f"gbits{l}"]))
             else:
                 self.gemm(ptr(a[f"y1_{l}"]), ptr(w[f"w1{l}"]), ptr(a[f"hff{l}"]), M, F, d, bias=fp.p_ptr(pre + "ffn.linear1.bias"),
                           act=L.ACT_RELU, drop1=(p, sites["ffn_a"]))
                 self.gemm(ptr(a[f"hff{l}"]), ptr(w[f"w2{l}"]), ptr(a[f"r2_{l}"]), M, d, F, bias=fp.p_ptr(pre + "ffn.linear2.bias"),
-                          drop1=(p, sites["ffn_b"]), drop2=(p, sites["drop2"]), residual=ptr(a[f"y1_{l}"]),
-                          ln=self._ln_f(pre + "ln2", a[f"x{l + 1}"], a[f"st2_{l}"]))
-            if not self.fuse_ln and not (self.fuse_ffn and self.ffn_ln):
-                self.ln_fwd(a[f"r2_{l}"], pre + "ln2", a[f"x{l + 1}"], a[f"st2_{l}"])
+                          drop1=(p, sites["ffn_b"]), drop2=(p, sites["drop2"]), residual=ptr(a[f"y1_{l}"]))
+            self.ln_fwd(a[f"r2_{l}"], pre + "ln2", a[f"x{l + 1}"], a[f"st2_{l}"])
         Lr = cfg.num_layers
         self.ln_fwd(a[f"x{Lr}"], "encoder.norm", a["zn"], a["stf"])
         z = a["zn"]
@@ -941,10 +837,9 @@ class Engine:
                  self.st_ptr, st)
             self._probs_hook(self.model.cross_attn.cross_attn.dropout, a["qkvx"], a["lsex"], B)
             self.gemm(ptr(a["ctxx"]), ptr(w["ox"]), ptr(a["rx"]), M, d, d, bias=fp.p_ptr("cross_attn.cross_attn.out_proj.bias"),
-                      drop1=(p, xs["drop1"]), residual=ptr(z), ln=self._ln_f("cross_attn.norm", a["zc"], a["stx"]))
-            if not self.fuse_ln:
-                call("eg_layernorm_fwd", ptr(a["rx"]), fp.p_ptr("cross_attn.norm.weight"), fp.p_ptr("cross_attn.norm.bias"),
-                     ptr(a["zc"]), ptr(a["stx"]), M, d, self.dtype, st)
+                      drop1=(p, xs["drop1"]), residual=ptr(z))
+            call("eg_layernorm_fwd", ptr(a["rx"]), fp.p_ptr("cross_attn.norm.weight"), fp.p_ptr("cross_attn.norm.bias"),
+                 ptr(a["zc"]), ptr(a["stx"]), M, d, self.dtype, st)
             z = a["zc"]
         self.z_final = z
         # heads (D:1193-1213)
@@ -1018,20 +913,13 @@ class Engine:
         other = g["dzB"]
 
         grouped = self._wgrad_group_plan() is not None
-        overlap = (grouped and os.environ.get("EYEGAZE_WGRAD_OVERLAP", "0") == "1" and self.device.type == "cuda"
-                   and not torch.cuda.is_current_stream_capturing())
-        if overlap and getattr(self, "_wg_side_stream", None) is None:
-            self._wg_side_stream = torch.cuda.Stream(self.device)
-        self._wg_side = self._wg_side_stream if overlap else None
         # with a gradient reducer listening (data parallel) the grouped launch is cut in two pieces (see _wgrad_group_plan);
         # EYEGAZE_WGRAD_PIECES=1 forces the cut without a reducer (bit-identity tests), =0 forbids it
         pcs = os.environ.get("EYEGAZE_WGRAD_PIECES", "")
-        pieced = grouped and not overlap and len(self._wg_plan["pieces"]) == 2 and pcs != "0" and (on_segment is not None or pcs == "1")
+        pieced = grouped and len(self._wg_plan["pieces"]) == 2 and pcs != "0" and (on_segment is not None or pcs == "1")
 
-        def attn_block_bwd(pre, l, x_in, dr, drm, kv_shift, site_attn, dx_out, dqkv, defer, ln_next=None):
-            """dr: grad of the pre-LN sum (residual path), drm: same, masked by the branch dropout.
-            ln_next: LayerNorm-backward spec of the layer BELOW, applied to this block's input gradient in the epilogue of
-            the q|k|v backward-data product (then dx_out is not materialised)."""
+        def attn_block_bwd(pre, l, x_in, dr, drm, kv_shift, site_attn, dx_out, dqkv, defer):
+            """dr: grad of the pre-LN sum (residual path), drm: same, masked by the branch dropout."""
             names = [pre + n for n in ("q_proj", "k_proj", "v_proj")]
             if not defer:
                 self.wgrad(ptr(drm), ptr(a[f"ctx{l}"]), 0, M, d, d, linear=[pre + "out_proj"])
@@ -1040,9 +928,7 @@ class Engine:
                  NB, S, H, kv_shift, self.dtype, p, site_attn, self.st_ptr, st)
             if not defer:
                 self.wgrad(ptr(dqkv), ptr(x_in), 0, M, 3 * d, d, linear=names)
-            self.gemm(ptr(dqkv), ptr(w[f"qkvT{l}"]), 0 if ln_next else ptr(dx_out), M, d, 3 * d, residual=ptr(dr), ln=ln_next)
-            if ln_next:
-                self._ln_b_finish(ln_next)
+            self.gemm(ptr(dqkv), ptr(w[f"qkvT{l}"]), ptr(dx_out), M, d, 3 * d, residual=ptr(dr))
 
         has_drop = p > 0
         gx = False
@@ -1074,13 +960,11 @@ class Engine:
             dqkv = g[f"dqkv{l}"] if grouped else g["dqkv"]
             s2 = self._ln_slot[pre + "ln2"] if grouped else None
             s1 = self._ln_slot[pre + "ln1"] if grouped else None
-            fuse = self.fuse_ln
-            if not (fuse and l < Lr - 1):      # (fused case: done by the layer above, in its q|k|v backward-data epilogue)
-                if has_drop:
-                    self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", g["dr"], dYf, d1=(p, sites["ffn_b"]),
-                                d2=(p, sites["drop2"]), slot=s2)
-                else:
-                    self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", dYf, None, slot=s2)
+            if has_drop:
+                self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", g["dr"], dYf, d1=(p, sites["ffn_b"]),
+                            d2=(p, sites["drop2"]), slot=s2)
+            else:
+                self.ln_bwd(dz, a[f"r2_{l}"], a[f"st2_{l}"], pre + "ln2", dYf, None, slot=s2)
             dr = g["dr"] if has_drop else dYf
             if not grouped:
                 self.wgrad(ptr(dYf), ptr(a[f"hff{l}"]), 0, M, d, F, linear=[pre + "ffn.linear2"])
@@ -1093,35 +977,14 @@ class Engine:
                 self.gemm(ptr(dYf), ptr(w[f"w2T{l}"]), ptr(dh), M, F, d, gate=ptr(a[f"hff{l}"]), gate_scale=sc)
             if not grouped:
                 self.wgrad(ptr(dh), ptr(a[f"y1_{l}"]), 0, M, F, d, linear=[pre + "ffn.linear1"])
-            if self.fuse_ffn:
-                if has_drop:
-                    self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", g["dr"], dYo, d1=(p, sites["drop1"]), slot=s1)
-                else:
-                    self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", dYo, None, slot=s1)
-            elif fuse:
-                # FFN-1 backward-data + residual gradient, with ln1's backward in the epilogue (dy1 is never written)
-                spec = (self._ln_b(pre + "ln1", a[f"r1_{l}"], a[f"st1_{l}"], g["dr"], dYo, d1=(p, sites["drop1"]), slot=s1)
-                        if has_drop else self._ln_b(pre + "ln1", a[f"r1_{l}"], a[f"st1_{l}"], dYo, None, slot=s1))
-                self.gemm(ptr(dh), ptr(w[f"w1T{l}"]), 0, M, d, F, residual=ptr(dr), ln=spec)
-                self._ln_b_finish(spec)
-            else:
+            if not self.fuse_ffn:
                 self.gemm(ptr(dh), ptr(w[f"w1T{l}"]), ptr(g["dy1"]), M, d, F, residual=ptr(dr))
-                if has_drop:
-                    self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", g["dr"], dYo, d1=(p, sites["drop1"]), slot=s1)
-                else:
-                    self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", dYo, None, slot=s1)
+            if has_drop:
+                self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", g["dr"], dYo, d1=(p, sites["drop1"]), slot=s1)
+            else:
+                self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", dYo, None, slot=s1)
             dr = g["dr"] if has_drop else dYo
-            ln_next = None
-            if fuse and l > 0:
-                pl, sl = f"encoder.layers.{l - 1}.", _layer_sites(l - 1)
-                dYf_n = g[f"dYf{l - 1}"] if grouped else (g["drm"] if has_drop else g["dr"])
-                sn = self._ln_slot[pl + "ln2"] if grouped else None
-                ln_next = (self._ln_b(pl + "ln2", a[f"r2_{l - 1}"], a[f"st2_{l - 1}"], g["dr"], dYf_n, d1=(p, sl["ffn_b"]),
-                                      d2=(p, sl["drop2"]), slot=sn)
-                           if has_drop else self._ln_b(pl + "ln2", a[f"r2_{l - 1}"], a[f"st2_{l - 1}"], dYf_n, None, slot=sn))
-            attn_block_bwd(pre + "mha.", l, a[f"x{l}"], dr, dYo, 0, sites["attn"], other, dqkv, grouped, ln_next)
-            if overlap:
-                self._wgrad_layer_async(l)
+            attn_block_bwd(pre + "mha.", l, a[f"x{l}"], dr, dYo, 0, sites["attn"], other, dqkv, grouped)
             dz, other = other, dz
             if not grouped:
                 seg(f"layer{l}")
@@ -1162,8 +1025,7 @@ class Engine:
         for ph in range(self.s):
             self.gemm(ptr(g["dy1pad"]), ptr(w["conv1T"]) + ph * d * self.J * d * es, ptr(g["dh0pad"]) + ph * d * es,
                       NB * self.U, d, self.J * d, a=rowmap(d, self.RY * d, self.U), c=rowmap(self.s * d, self.R0 * d, self.U),
-                      gate=ptr(a["h0pad"]) + ph * d * es, gate_scale=sc01,
-                      w_frag=(ptr(w["conv1Tf"]) + ph * d * self.J * d * es) if self.tall_conv else 0)
+                      gate=ptr(a["h0pad"]) + ph * d * es, gate_scale=sc01)
         h0map = rowmap(d, self.R0 * d, self.T1)
         self.wgrad(ptr(g["dh0pad"]) + self.pad * d * es, ptr(a["xt"]), fp.g_ptr("temporal_conv.convs.0.weight"),
                    NB * self.T1, d, self.K0, y=h0map, x=rowmap(self.s * self.Cp, self.Tp * self.Cp, self.T1),

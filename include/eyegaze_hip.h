@@ -143,37 +143,13 @@ typedef struct eg_gemm_desc {
   float gate_scale; /* 1/(1-p) of the dropout that followed the gated ReLU in the forward pass, else 1 */
   int32_t a_seg_len;    /* 0, or: an A row is K/a_seg_len segments of a_seg_len contiguous elements ... */
   int64_t a_seg_stride; /* ... a_seg_stride elements apart (rows of a 2-D convolution window, D:74) */
-  /* Row-complete tile (N == 256 only): a workgroup owns whole output rows, so the LayerNorm(eps 1e-5) next to the product
-   * runs in the epilogue (A:293,295 and their backward).  row_tile != 0 selects the tile without a LayerNorm.
-   *   ln_mode 1 (forward):  C = v (the epilogue value above, required); ln_out[M,256] = LN(v as stored)*gamma+beta;
-   *                         ln_stats[M,2] = (mean, rstd)
-   *   ln_mode 2 (backward): dy = v (C optional); against the saved rows ln_x[M,256] and ln_stats: ln_out = dx,
-   *                         ln_out2 = ln_drop2(ln_drop1(dx)) or NULL, ln_partial[ceil(M/64)][2][256] = per-workgroup
-   *                         (sum_m dy*xhat | sum_m dy), to be summed in block order (eg_reduce_partials / eg_reduce_table) */
-  int32_t ln_mode, row_tile;
-  const float* ln_gamma;
-  const float* ln_beta;
-  const void* ln_x;
-  float* ln_stats;
-  void* ln_out;
-  void* ln_out2;
-  float* ln_partial;
-  float ln_drop1_p, ln_drop2_p;
-  uint32_t ln_drop1_site, ln_drop2_site;
-  /* Optional: the same W (N == 256 rows) in MFMA-fragment order as written by eg_frag_order_rows.  With it, deep products
-   * (K >= 1536, K % 256 == 0, 16-bit dtypes) run on the one-wave-per-SIMD tall tile whose weights go straight to registers. */
-  const void* W_frag;
 } eg_gemm_desc;
 int eg_gemm_nt(const eg_gemm_desc* d, void* stream);
 /* Which kernel eg_gemm_nt launches for `d` (no launch; a measurement aid so that per-launch timings can be attributed):
  * EG_ROUTE_TILED gemm_nt_kernel (128x128 tile), EG_ROUTE_WIDE gemm_nt_wide_kernel (160x256, N == 256),
- * EG_ROUTE_ROWSTREAM rs_gemm_kernel (K == 256, register-stationary weights), EG_ROUTE_ROWTILE gemm_nt_row_kernel,
- * EG_ROUTE_TALL gemm_nt_tall_kernel (N == 256, K >= 1536, W_frag given: one wave per SIMD, weights straight to registers). */
-enum { EG_ROUTE_TILED = 0, EG_ROUTE_WIDE = 1, EG_ROUTE_ROWSTREAM = 2, EG_ROUTE_ROWTILE = 3, EG_ROUTE_TALL = 5 };
+ * EG_ROUTE_ROWSTREAM rs_gemm_kernel (K == 256, register-stationary weights). */
+enum { EG_ROUTE_TILED = 0, EG_ROUTE_WIDE = 1, EG_ROUTE_ROWSTREAM = 2 };
 int eg_gemm_nt_route(const eg_gemm_desc* d);
-/* `count` stacked [256, ldw] row-major 16-bit weights (K columns used) -> count x [K/32][4][4][64][8]: the fragment order
- * eg_gemm_desc.W_frag expects */
-int eg_frag_order_rows(const void* src, void* dst, int K, int ldw, int count, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * eg_ffn_chain — the two products of the position-wise feed-forward block (A:264-272) in one launch, d_model == 256:
@@ -184,8 +160,6 @@ int eg_frag_order_rows(const void* src, void* dst, int K, int ldw, int count, vo
  *   scaled by gate_scale), W2 = linear1^T, residual = the gradient arriving on the skip path.
  *   Bit-identical to the two eg_gemm_nt launches it replaces (same MFMA chains, epilogue order and dropout indices m*N + n);
  *   the hidden rows cross HBM once (the stored H) instead of three times.  16-bit dtypes, F % 128 == 0, strides in elements.
- *   W2 == C == NULL: product 1 only, H = drop_h(act1(A * W1^T + bias1)) -- a K = 256 product on the same data path (the fused
- *   q|k|v projection, A:203-205, with F = 768).
  * ------------------------------------------------------------------------------------------- */
 typedef struct eg_ffn_desc {
   const void* A;        /* [M, 256], row stride lda */
@@ -208,12 +182,6 @@ typedef struct eg_ffn_desc {
   float drop_h_p, drop_c1_p, drop_c2_p;
   uint32_t drop_h_site, drop_c1_site, drop_c2_site;
   float gate_scale;
-  /* Optional (forward form): LayerNorm(eps 1e-5) of the C rows as stored, in the same launch (A:295: the encoder layer's norm2
-   * follows this block): ln_out[M,256] (row stride ldc) = LN(C) * ln_gamma + ln_beta, ln_stats[M,2] = (mean, rstd). */
-  const float* ln_gamma;
-  const float* ln_beta;
-  void* ln_out;
-  float* ln_stats;
 } eg_ffn_desc;
 int eg_ffn_chain(const eg_ffn_desc* d, void* stream);
 int64_t eg_ffn_gate_bits_bytes(int M, int F);

@@ -23,6 +23,7 @@ if [ "${PMC:-1}" = "1" ]; then
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 bench.py --workload $WL --dtype $DT --no-cpu-baseline --steps 6 --warmup 2 $EXTRA > $O/pmc_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 bench.py --workload $WL --dtype $DT --no-cpu-baseline --steps 6 --warmup 2 $EXTRA > $O/pmc_write.log 2>&1
   python profiles/tools/pmc_by_kernel.py $O/pmc_fetch $O/pmc_write $O/pmc_by_kernel.json ${DOMINANT:-gemm_nt_wide_kernel} $O/pmc_dominant.json > $O/pmc_by_kernel.txt
+  python profiles/tools/pmc_for_bench.py $O/pmc_by_kernel.json $O/pmc_for_bench.json >> $O/pmc_by_kernel.txt   # -> profiles/r03_pmc_<workload>_<dtype>.json
 fi
 rm -rf $O/trace $O/pmc_fetch $O/pmc_write   # raw traces are large; the summaries above are what gets committed
 head -n 52 $O/kernel_summary.txt

@@ -21,7 +21,7 @@ def bench(M, N, K, residual=0, gate=0, act=0, drop=0.0, ln=0, reps=40):
     d.drop1_p, d.drop1_site, d.gate_scale = drop, 5, 1.0
     if ln:
         gm = torch.ones(N, device=dev); Y = torch.zeros(M, N, device=dev, dtype=td); S = torch.zeros(M, 2, device=dev)
-        d.ln_mode, d.ln_gamma, d.ln_beta, d.ln_out, d.ln_stats = 1, ptr(gm), ptr(gm), ptr(Y), ptr(S)
+        raise SystemExit('the LayerNorm-epilogue tile was removed in round 3')
     for _ in range(5): call("eg_gemm_nt", C.byref(d), 0)
     torch.cuda.synchronize()
     # the launches are replayed from a captured graph: the Python / ctypes launch path costs more host time per call than

@@ -176,67 +176,3 @@ def test_ffn_chain_argument_checks():
     d.F, d.dtype = 128, L.EG_F32                                                    # fp32 keeps the two-launch path
     with pytest.raises(L.EgError):
         call("eg_ffn_chain", C.byref(d), 0)
-
-
-@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("M", [33280, 1037, 7])
-def test_ffn_chain_layernorm_epilogue_matches_the_layernorm_kernel(M, dtype):
-    """norm2 in the FFN chain's epilogue: the block output is untouched, and LN(C) / (mean, rstd) equal what eg_layernorm_fwd
-    computes from the stored C rows (same two-pass statistics, a different summation tree: one rounding of the storage type)."""
-    F, p = 1024, 0.1
-    t = TDT[dtype]
-    o = operands(M, F, dtype, seed=21)
-    H0, C0 = one_launch(o, M, F, dtype, "fwd", p)
-    g = torch.Generator(device="cpu").manual_seed(5)
-    gamma, beta = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV), (0.1 * torch.randn(D, generator=g)).to(DEV)
-    y = torch.full((M, D), 7.0, device=DEV, dtype=t)
-    stats = torch.zeros(M, 2, device=DEV)
-    H1 = torch.full((M, F), 7.0, device=DEV, dtype=t)
-    C1 = torch.full((M, D), 7.0, device=DEV, dtype=t)
-    d = FfnDesc()
-    w1f, w2f = frag_pack(o["W1"], 3, dtype), frag_pack(o["W2"], 5, dtype)
-    d.A, d.W1, d.W2, d.H, d.C, d.state = ptr(o["A"]), ptr(w1f), ptr(w2f), ptr(H1), ptr(C1), ptr(o["st"])
-    d.lda, d.ldh, d.ldc, d.ldg, d.ldr, d.M, d.F, d.dtype = D, F, D, F, D, M, F, dtype
-    d.bias1, d.bias2, d.act1, d.residual = ptr(o["b1"]), ptr(o["b2"]), L.ACT_RELU, ptr(o["A"])
-    d.drop_h_p, d.drop_h_site, d.drop_c1_p, d.drop_c1_site, d.drop_c2_p, d.drop_c2_site = p, 21, p, 22, p, 23
-    d.ln_gamma, d.ln_beta, d.ln_out, d.ln_stats = ptr(gamma), ptr(beta), ptr(y), ptr(stats)
-    call("eg_ffn_chain", C.byref(d), 0)
-    torch.cuda.synchronize()
-    assert torch.equal(H1, H0) and torch.equal(C1, C0)
-    y_ref = torch.empty_like(y)
-    st_ref = torch.zeros_like(stats)
-    call("eg_layernorm_fwd", ptr(C0), ptr(gamma), ptr(beta), ptr(y_ref), ptr(st_ref), M, D, dtype, 0)
-    torch.cuda.synchronize()
-    assert float((stats - st_ref).abs().max()) <= 2e-5 * max(1.0, float(st_ref.abs().max()))
-    ulp = 2.0 ** -8 if dtype == L.EG_BF16 else 2.0 ** -11
-    err = (y.float() - y_ref.float()).abs()
-    assert float((err / (y_ref.float().abs() + 1.0)).max()) <= 2 * ulp
-    assert float((err > 0).float().mean()) < 0.02          # only rounding-boundary cases differ
-
-
-@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("M,F,act,p", [(33280, 768, 0, 0.0), (1037, 768, 0, 0.0), (7, 128, 1, 0.1), (4160, 1024, 1, 0.1)])
-def test_product_one_only_form_is_bit_identical_to_gemm_nt(M, F, act, p, dtype):
-    """W2 == C == NULL: eg_ffn_chain is a K = 256 product (the fused q|k|v projection runs on it); same chains, same epilogue."""
-    t = TDT[dtype]
-    o = operands(M, F, dtype, seed=31)
-    ref = torch.full((M, F), 7.0, device=DEV, dtype=t)
-    d = GemmDesc()
-    d.A, d.W, d.C, d.bias, d.state = ptr(o["A"]), ptr(o["W1"]), ptr(ref), ptr(o["b1"]), ptr(o["st"])
-    d.a, d.c = rowmap(D), rowmap(F)
-    d.r, d.p = d.c, d.c
-    d.M, d.N, d.K, d.ldw, d.dtype, d.act = M, F, D, D, dtype, act
-    d.drop1_p, d.drop1_site = p, 21
-    call("eg_gemm_nt", C.byref(d), 0)
-    H = torch.full((M, F), 7.0, device=DEV, dtype=t)
-    f = FfnDesc()
-    w1f = frag_pack(o["W1"], 3, dtype)
-    f.A, f.W1, f.H, f.bias1, f.state = ptr(o["A"]), ptr(w1f), ptr(H), ptr(o["b1"]), ptr(o["st"])
-    f.lda, f.ldh, f.M, f.F, f.dtype, f.act1 = D, F, M, F, dtype, act
-    f.drop_h_p, f.drop_h_site = p, 21
-    call("eg_ffn_chain", C.byref(f), 0)
-    torch.cuda.synchronize()
-    assert torch.equal(H, ref), float((H.float() - ref.float()).abs().max())
-    f.C = ptr(ref)                      # C without W2: refused
-    with pytest.raises(L.EgError):
-        call("eg_ffn_chain", C.byref(f), 0)

@@ -513,131 +513,6 @@ def test_fuzzy_gating_fusion_large_batch_reduction():
 # ------------------------------------------------------------------------------------------------
 # row-complete GEMM tile (N == 256) with LayerNorm in the epilogue (eg_gemm_desc.ln_*)
 # ------------------------------------------------------------------------------------------------
-def _row_gemm(A, W, M, K, dtype, *, out, bias=None, residual=None, state=None, drop1=(0.0, 0), ln=None, row_tile=0):
-    d = GemmDesc()
-    d.A, d.W, d.C = ptr(A), ptr(W), (ptr(out) if out is not None else None)
-    d.bias, d.residual = ptr(bias) or None, ptr(residual) or None
-    d.state = ptr(state) or None
-    d.a, d.c = rowmap(K), rowmap(256)
-    d.r, d.p = d.c, d.c
-    d.M, d.N, d.K, d.ldw, d.act, d.dtype = M, 256, K, K, 0, dtype
-    d.drop1_p, d.drop1_site = drop1
-    d.gate_scale = 1.0
-    d.row_tile = row_tile
-    if ln:
-        for k, v in ln.items():
-            setattr(d, k, v)
-    call("eg_gemm_nt", C.byref(d), 0)
-    torch.cuda.synchronize()
-
-
-@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16, L.EG_F32])
-@pytest.mark.parametrize("M,K", [(520, 256), (64, 64), (1000, 1024), (130, 768)])
-def test_gemm_row_tile_matches_plain_tile(dtype, M, K):
-    g = torch.Generator().manual_seed(M + K)
-    A = torch.randn(M, K, generator=g).to(DT[dtype]).to(DEV)
-    W = (torch.randn(256, K, generator=g) / math.sqrt(K)).to(DT[dtype]).to(DEV)
-    bias = torch.randn(256, generator=g).to(DEV)
-    res = torch.randn(M, 256, generator=g).to(DT[dtype]).to(DEV)
-    ref = gemm_nt(A, W, M, 256, K, dtype, bias=bias, residual=res)
-    out = torch.full((M + 3, 256), 7.0, device=DEV, dtype=DT[dtype])     # rows beyond M must stay untouched
-    _row_gemm(A, W, M, K, dtype, out=out, bias=bias, residual=res, row_tile=1)
-    torch.testing.assert_close(out[:M].float().cpu(), ref.float().cpu(), rtol=0, atol=0)   # same K order, same epilogue
-    assert float(out[M:].float().min()) == 7.0
-
-
-@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16, L.EG_F32])
-@pytest.mark.parametrize("M,K", [(520, 256), (97, 1024)])
-def test_gemm_row_layernorm_forward(dtype, M, K):
-    g = torch.Generator().manual_seed(M * 3 + K)
-    A = torch.randn(M, K, generator=g).to(DT[dtype]).to(DEV)
-    W = (torch.randn(256, K, generator=g) / math.sqrt(K)).to(DT[dtype]).to(DEV)
-    bias, gamma, beta = (torch.randn(256, generator=g).to(DEV) for _ in range(3))
-    res = torch.randn(M, 256, generator=g).to(DT[dtype]).to(DEV)
-    out = torch.zeros(M, 256, device=DEV, dtype=DT[dtype])
-    y = torch.zeros(M, 256, device=DEV, dtype=DT[dtype])
-    stats = torch.zeros(M, 2, device=DEV)
-    _row_gemm(A, W, M, K, dtype, out=out, bias=bias, residual=res,
-              ln=dict(ln_mode=1, ln_gamma=ptr(gamma), ln_beta=ptr(beta), ln_out=ptr(y), ln_stats=ptr(stats)))
-    r = A.double().cpu() @ W.double().cpu().T + bias.double().cpu() + res.double().cpu()
-    torch.testing.assert_close(out.cpu().double(), r, **tol(dtype))
-    rs = out.cpu().double()                           # LayerNorm acts on the STORED sum
-    mean, var = rs.mean(1, keepdim=True), rs.var(1, unbiased=False, keepdim=True)
-    yref = (rs - mean) / torch.sqrt(var + 1e-5) * gamma.double().cpu() + beta.double().cpu()
-    torch.testing.assert_close(y.cpu().double(), yref, **tol(dtype))
-    torch.testing.assert_close(stats[:, 0].cpu().double(), mean[:, 0], rtol=1e-5, atol=1e-5)
-    torch.testing.assert_close(stats[:, 1].cpu().double(), 1 / torch.sqrt(var[:, 0] + 1e-5), rtol=1e-4, atol=1e-5)
-    # and equals the stand-alone LayerNorm kernel on the stored rows
-    y2, st2 = torch.zeros_like(y), torch.zeros_like(stats)
-    call("eg_layernorm_fwd", ptr(out), ptr(gamma), ptr(beta), ptr(y2), ptr(st2), M, 256, dtype, 0)
-    torch.cuda.synchronize()
-    torch.testing.assert_close(y.float().cpu(), y2.float().cpu(), rtol=0, atol=1e-2 if dtype != L.EG_F32 else 1e-5)
-
-
-@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16, L.EG_F32])
-@pytest.mark.parametrize("M,K,p", [(520, 1024, 0.0), (200, 768, 0.1), (64, 256, 0.1)])
-def test_gemm_row_layernorm_backward(dtype, M, K, p):
-    """dy = A W^T + residual; LayerNorm backward in the epilogue == the stand-alone kernel fed with dy, and == autograd."""
-    g = torch.Generator().manual_seed(M + 11 * K)
-    A = (torch.randn(M, K, generator=g) * 0.3).to(DT[dtype]).to(DEV)
-    W = (torch.randn(256, K, generator=g) / math.sqrt(K)).to(DT[dtype]).to(DEV)
-    res = torch.randn(M, 256, generator=g).to(DT[dtype]).to(DEV)
-    x = (torch.randn(M, 256, generator=g) * 2 + 0.5).to(DT[dtype]).to(DEV)
-    gamma = torch.randn(256, generator=g).to(DEV)
-    xd = x.double().cpu()
-    mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
-    stats = torch.cat([mean, 1 / torch.sqrt(var + 1e-5)], 1).float().to(DEV)
-    st = dev_state(seed=77)
-    nblk = (M + 63) // 64
-    dy_out = torch.zeros(M, 256, device=DEV, dtype=DT[dtype])
-    dx, dxd = torch.zeros_like(dy_out), torch.zeros_like(dy_out)
-    part = torch.zeros(nblk, 2, 256, device=DEV)
-    _row_gemm(A, W, M, K, dtype, out=dy_out, residual=res, state=st,
-              ln=dict(ln_mode=2, ln_gamma=ptr(gamma), ln_x=ptr(x), ln_stats=ptr(stats), ln_out=ptr(dx), ln_out2=ptr(dxd),
-                      ln_partial=ptr(part), ln_drop1_p=p, ln_drop1_site=5))
-    # autograd reference on the fp64 dy
-    dy = A.double().cpu() @ W.double().cpu().T + res.double().cpu()
-    torch.testing.assert_close(dy_out.cpu().double(), dy, **tol(dtype))
-    xr = xd.clone().requires_grad_(True)
-    gr = gamma.double().cpu().clone().requires_grad_(True)
-    br = torch.zeros(256, dtype=torch.float64, requires_grad=True)
-    torch.nn.functional.layer_norm(xr, (256,), gr, br, 1e-5).backward(dy)
-    k = 3.0 if dtype != L.EG_F32 else 20.0       # dx sums 256 products per row
-    torch.testing.assert_close(dx.cpu().double(), xr.grad, **tol(dtype, k))
-    torch.testing.assert_close(part[:, 0].sum(0).cpu().double(), gr.grad, rtol=2e-2 if dtype != L.EG_F32 else 1e-4, atol=0.3 if dtype != L.EG_F32 else 1e-3)
-    torch.testing.assert_close(part[:, 1].sum(0).cpu().double(), br.grad, rtol=2e-2 if dtype != L.EG_F32 else 1e-4, atol=0.3 if dtype != L.EG_F32 else 1e-3)
-    # the dropout-masked copy uses the same (seed, site, element) mask as the stand-alone kernel
-    dx2, dxd2, part2 = torch.zeros_like(dx), torch.zeros_like(dx), torch.zeros(512, 2, 256, device=DEV)
-    call("eg_layernorm_bwd", ptr(dy_out), ptr(x), ptr(stats), ptr(gamma), ptr(dx2), ptr(dxd2), ptr(part2), 512, 512, M, 256, dtype,
-         p, 5, 0.0, 0, ptr(st), 0)
-    torch.cuda.synchronize()
-    keep_a, keep_b = dxd.float().cpu() != 0, dxd2.float().cpu() != 0
-    nz = (dx.float().cpu() != 0) & (dx2.float().cpu() != 0)
-    assert bool((keep_a == keep_b)[nz].all())
-    if p > 0:
-        frac = float(keep_a[nz].float().mean())
-        assert abs(frac - (1 - p)) < 0.02, frac
-        sel = keep_a & nz
-        torch.testing.assert_close(dxd.float().cpu()[sel], (dx.float().cpu() / (1 - p))[sel], rtol=1e-2, atol=1e-3)
-    # C may be omitted in backward mode
-    dx3 = torch.zeros_like(dx)
-    _row_gemm(A, W, M, K, dtype, out=None, residual=res, state=st,
-              ln=dict(ln_mode=2, ln_gamma=ptr(gamma), ln_x=ptr(x), ln_stats=ptr(stats), ln_out=ptr(dx3), ln_partial=ptr(part)))
-    torch.testing.assert_close(dx3.float().cpu(), dx.float().cpu(), rtol=0, atol=0)
-
-
-def test_gemm_row_tile_rejects_other_widths():
-    A = torch.zeros(64, 64, device=DEV, dtype=torch.bfloat16)
-    W = torch.zeros(128, 64, device=DEV, dtype=torch.bfloat16)
-    d = GemmDesc()
-    d.A, d.W, d.C = ptr(A), ptr(W), ptr(torch.zeros(64, 128, device=DEV, dtype=torch.bfloat16))
-    d.a, d.c = rowmap(64), rowmap(128)
-    d.r, d.p = d.c, d.c
-    d.M, d.N, d.K, d.ldw, d.dtype, d.row_tile = 64, 128, 64, 64, L.EG_BF16, 1
-    with pytest.raises(L.EgError):
-        call("eg_gemm_nt", C.byref(d), 0)
-
-
 def test_reduce_table_wide_and_narrow_entries():
     """eg_reduce_table: entries with few splits take the one-column-per-thread path, entries with many short slabs the
     8-column x 32-lane path; block ranges follow include/eyegaze_hip.h (EG_REDUCE_WIDE_SPLITS)."""

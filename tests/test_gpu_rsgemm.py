@@ -25,14 +25,13 @@ CASES = [
     # M, N, residual, gate, act, drop, out_pre, ln
     (33280, 768, 0, 0, 0, 0.0, 0, 0),      # q|k|v
     (33280, 256, 1, 0, 0, 0.1, 0, 0),      # out-proj + dropout + residual
-    (33280, 256, 1, 0, 0, 0.1, 0, 1),      # ... with LayerNorm in the epilogue
     (33280, 1024, 0, 0, 1, 0.1, 0, 0),     # FFN-1: ReLU + dropout
     (33280, 1024, 0, 1, 0, 0.0, 0, 0),     # FFN-2 backward-data: gate
     (33280, 256, 0, 0, 0, 0.0, 0, 0),      # out-proj backward-data
     (520, 768, 0, 0, 0, 0.0, 0, 0),        # B = 4: fewer blocks than CUs
     (1037, 256, 1, 0, 1, 0.2, 1, 0),       # ragged M, out_pre
     (16 * 256 * 23 + 5, 512, 0, 1, 0, 0.1, 0, 0),   # 23+ blocks per workgroup: the ring wraps several times
-    (8, 256, 1, 0, 0, 0.0, 0, 1),          # less than one block
+    (8, 256, 1, 0, 0, 0.0, 0, 0),          # less than one block
 ]
 
 
@@ -59,8 +58,7 @@ def run_case(M, N, residual, gate, act, drop, out_pre, ln, seed=0, K=256):
     d.r, d.p = d.c, d.c
     d.M, d.N, d.K, d.ldw, d.act, d.dtype = M, N, K, K, act, L.EG_BF16
     d.drop1_p, d.drop1_site, d.gate_scale = drop, 11, 1.25 if gate else 1.0
-    if ln:
-        d.ln_mode, d.ln_gamma, d.ln_beta, d.ln_out, d.ln_stats = 1, ptr(gam), ptr(bet), ptr(y), ptr(stats)
+    assert not ln      # (the LayerNorm-epilogue tile these cases once exercised was measured no faster and removed in round 3)
     call("eg_gemm_nt", C.byref(d), 0)
     torch.cuda.synchronize()
     t = dict(A=A, W=W, b=b, R=R, G=G, gam=gam, bet=bet)
