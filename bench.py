@@ -461,7 +461,9 @@ def main():
     opt = HipAdamW(model, lr=1e-4, weight_decay=0.01)
     x1, x2, labels = randn_windows(B, C, T, seed=1234 + rank, num_classes=3, device=dev)
     ranges = bucket_ranges(fp.names, fp.offsets, fp.total, model.cfg.num_layers, model.cfg.use_cross_attention)
-    reducer = GradAllReducer(fp.grad, ranges, force=args.force_dist) if use_dist else None
+    from eyegaze_multimodal_amd.ddp import coalesce_groups
+    reducer = (GradAllReducer(fp.grad, ranges, force=args.force_dist, groups=coalesce_groups(ranges, model.cfg.num_layers))
+               if use_dist else None)
     one = torch.ones(1, device=dev)
 
     from eyegaze_multimodal_amd.graph import GraphedStep

@@ -99,26 +99,6 @@ def test_full_size_train_step_moves_every_parameter_and_stays_finite():
         assert frac > 0.5 or n.endswith("k_proj.bias"), (n, frac)
 
 
-def test_overlapped_weight_gradient_launches_are_bit_identical(monkeypatch):
-    """EYEGAZE_WGRAD_OVERLAP=1 queues each layer's weight-gradient products on a side stream behind an event; the same
-    kernels write the same partial slabs, so the reduced gradients must equal the single grouped launch bit for bit."""
-    z, kw, cfg, sd, model = build("cfg3_xattn", "bf16")
-    model.train()
-    x1, x2, y = _inputs(z)
-    one = torch.ones(1, device=DEV)
-    grads = []
-    for flag in ("0", "1", "1"):
-        monkeypatch.setenv("EYEGAZE_WGRAD_OVERLAP", flag)
-        eng = model.engine(B, 1024, torch.device(DEV))
-        eng.set_state(seed=99, lr=0.0, step=1)
-        eng.forward(x1, x2, y, train=True)
-        eng.backward(gloss=one)
-        torch.cuda.synchronize()
-        assert (eng._wg_side is not None) == (flag == "1")
-        grads.append(model._flat.grad.clone())
-    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[1], grads[2])
-
-
 def test_two_piece_weight_gradient_launch_is_bit_identical_and_releases_buckets_early(monkeypatch):
     """Data-parallel runs cut the grouped weight-gradient launch in two (layers L-1..L/2, then L/2-1..0) so the upper layers'
     gradient buckets can start their all-reduce while the lower layers are still in backward.  The cut changes neither a
@@ -163,3 +143,28 @@ def test_two_piece_weight_gradient_launch_is_bit_identical_and_releases_buckets_
     assert calls_at[f"layer{L_ // 2 - 1}"] - calls_at["cross"] > 10
     # launches were issued between the release of layer L/2 and the release of layer L/2-1 (the lower half's backward)
     assert calls_at[f"layer{L_ // 2 - 1}"] - calls_at[f"layer{L_ // 2}"] > 10
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_fresh_models_at_full_size_with_and_without_the_attention_block(dtype, monkeypatch):
+    """Round 3 saw ONE intermittent GPU memory access fault in an eval forward at B = 128 / 256 right after a fresh model was built
+    (never reproduced).  This regression walks that scenario on purpose: several freshly built models, first forward at
+    full size, with the window-resident attention block off and on -- outputs must be finite, deterministic and bit-identical
+    between the two (the block replaces three launches bit for bit)."""
+    outs = {}
+    for flag in ("0", "1", "1", "0", "1"):
+        monkeypatch.setenv("EYEGAZE_ATTN_BLOCK", flag)
+        z, kw, cfg, sd, model = build("cfg3_xattn", dtype)
+        model.eval()
+        x1, x2, y = _inputs(z)
+        with torch.no_grad():
+            lg = model(x1, x2, y)["logits"].clone()
+            lg2 = model(x1[:128], x2[:128])["logits"].clone()
+        torch.cuda.synchronize()
+        assert torch.isfinite(lg).all() and torch.equal(lg[:128], lg2)
+        eng = model.engine(B, 1024, x1.device)
+        assert eng.attn_block == (flag == "1")
+        outs.setdefault(flag, lg)
+        assert torch.equal(outs[flag], lg)
+        del model, eng
+    assert torch.equal(outs["0"], outs["1"])
