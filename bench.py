@@ -105,13 +105,27 @@ def launch_ranks(plans, argv=None, timeout_s: float = None, poll_s: float = 0.2)
     return rc
 
 
+def granted_cores():
+    """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box shows 256 cores in the
+    affinity mask but grants a 16-CPU quota per GPU: 256 threads on a 16-CPU quota run the oracle several times SLOWER than 16)."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(per) + 0.5))
+    except (OSError, ValueError):
+        pass
+    return min(aff, quota) if quota else aff, {"affinity": aff, "cgroup_quota": quota, "cpu_count": os.cpu_count()}
+
+
 def cpu_baseline(kw, C, T, Bc=256, seconds_budget=30.0):
     """The CPU oracle (oracle/dual_eeg_oracle.py, kind 'port') timed on this host: train-mode forward + backward +
     clip + AdamW on the same synthetic workload at the same batch (B = 256, fp32, all granted cores,
     1 warm-up step, then up to 3 timed steps inside a bounded time budget)."""
     from oracle import dual_eeg_oracle as O
     from eyegaze_multimodal_amd.data import randn_windows
-    cores = len(os.sched_getaffinity(0))            # every core this process may run on (BASELINE.md §4: all cores, count stated)
+    cores, avail = granted_cores()                  # every core this process is granted (BASELINE.md §4: all cores, count stated)
     torch.set_num_threads(cores)
     cfg = O.ModelCfg(in_channels=C, max_len=T // 4, **kw)
     sd = O.synthetic_state_dict(cfg, seed=1)
@@ -135,7 +149,7 @@ def cpu_baseline(kw, C, T, Bc=256, seconds_budget=30.0):
         step(n + 1)
         n += 1
     dt = (time.perf_counter() - t0) / n
-    return {"value": round(Bc / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "cores_available": os.cpu_count(),
+    return {"value": round(Bc / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "cores_available": avail,
             "kind": "port",
             "sample": f"oracle fwd+bwd+clip+AdamW, train mode, B={Bc} windows of the same synthetic workload, {n} timed steps after 1 warm-up"}
 
@@ -328,7 +342,7 @@ def cpu_baseline_mm5(tr, C, T, F_, W_, Bc=256, seconds_budget=30.0):
     from oracle import dual_eeg_oracle as O
     from oracle.multimodal_oracle import Stepper
     from eyegaze_multimodal_amd.train_multimodal_fuzzy_fusion import synth_multimodal
-    cores = len(os.sched_getaffinity(0))
+    cores, avail = granted_cores()
     torch.set_num_threads(cores)
     m = tr.model
     gaze = copy.deepcopy(m.gaze_encoder).cpu().float()
@@ -347,7 +361,7 @@ def cpu_baseline_mm5(tr, C, T, F_, W_, Bc=256, seconds_budget=30.0):
         st.step(*batch)
         n += 1
     dt = (time.perf_counter() - t0) / n
-    return {"value": round(Bc / dt, 3), "unit": "samples/s", "cores": cores, "cores_available": os.cpu_count(), "kind": "port",
+    return {"value": round(Bc / dt, 3), "unit": "samples/s", "cores": cores, "cores_available": avail, "kind": "port",
             "sample": f"multimodal oracle step (image CNN + EEG oracle + fuzzy fusion + clip + AdamW), eval-mode dropout, B={Bc}, "
                       f"{n} timed steps after 1 warm-up"}
 

@@ -6,7 +6,8 @@ SURVEY.md 8c evidence: reference fp32 vs fp64 differs by ~2e-7 on logits):
   bf16 compute (bf16 storage, fp32 accumulate):  measured max |dlogit| 1.74e-2 over all fixtures -> gate 3e-2; argmax equal
       wherever the reference's top-2 margin exceeds 4e-2; stage tensors rtol 3e-2 of their max-abs.
   f32 compute (exact-fp32 MFMA): measured max |dlogit| 1.8e-6 -> gate 4e-6 (SURVEY 8c proposed 1e-5), argmax on every sample;
-      configurations with synchrony tokens 5e-5 (sign()-based PLI / wPLI: 2.2e-5 measured on the 512-sample fixture).
+      synchrony tokens included on these fixtures (1.8e-6; over 512 samples the sign()-based PLI / wPLI add up to 2.2e-5, which
+      tests/test_gpu_logits512.py attributes to the flipped entries by injecting the reference's connectivity).
 """
 import numpy as np
 import pytest
@@ -106,9 +107,9 @@ def test_eval_forward_matches_reference(name, kind):
 def test_f32_forward_and_gradients_are_tight(name, kind):
     """compute_dtype='f32' (exact-fp32 MFMA + fmaf attention): logits within 4e-6 of the reference's fp32 CPU
     result (measured 1.8e-6), argmax bit-exact on every sample, every parameter gradient within 1e-3 relative (Frobenius;
-    measured 6.6e-4).  Configurations with synchrony tokens get 5e-5 / 2e-2: the sign()-based PLI / wPLI features are
-    discontinuous (one flipped sample of T=1024 moves an entry by 2e-3; 2.2e-5 on logits over 512 samples, gradient of the
-    tokenizer's instance-norm gain 1.45e-2) and the radix-2 LDS FFT rounds differently from pocketfft."""
+    measured 6.6e-4).  Configurations with synchrony tokens keep the logit gate and get 2e-2 on gradients: the sign()-based PLI /
+    wPLI features are discontinuous (one flipped sample of T=1024 moves an entry by 2e-3: gradient of the tokenizer's instance-norm
+    gain 1.45e-2) and the radix-2 LDS FFT rounds differently from pocketfft."""
     z, kw, cfg, sd, model = build(name, "f32")
     model.eval()
     x1, x2, labels = t(z[f"{kind}/eeg1"]).to(DEV), t(z[f"{kind}/eeg2"]).to(DEV), t(z["labels"]).to(DEV)
@@ -117,7 +118,10 @@ def test_f32_forward_and_gradients_are_tight(name, kind):
     loss.backward()
     torch.cuda.synchronize()
     ibs = cfg.use_ibs
-    ltol, gtol = (5e-5, 2e-2) if ibs else ((4e-6, 1e-3) if cfg.use_spectrogram else (4e-6, 1e-3))
+    # logits: measured <= 1.8e-6 on every fixture, synchrony tokens included (profiles/r03_parity_table.json: on these 4-sample
+    # fixtures NO PLI entry moves at C = 8 and 1-4 of 6 144 move by exactly 2/T at C = 32), so one gate; the sign()-based features
+    # still loosen the GRADIENT gate of the tokenizer's instance-norm gain (1.45e-2 measured)
+    ltol, gtol = (4e-6, 2e-2) if ibs else (4e-6, 1e-3)
     got = out["logits"].detach().cpu().numpy()
     assert np.abs(got - z[f"{kind}/out/logits"]).max() <= ltol
     assert (got.argmax(-1) == z[f"{kind}/out/argmax"]).all()
