@@ -5,7 +5,8 @@ Runs ONLY in the build container (the reference is imported by path from /root/r
 For each BASELINE.json config (+ the reference's default flags, A5) the reference model (eval mode, CPU fp32, the same
 deterministic synthetic weights as every other fixture) classifies N = 512 window pairs.  The inputs are NOT stored: they are
 the throughput generator of SURVEY 8d, `randn_windows(N, 8, 1024, seed)` -- torch's CPU generator is reproducible, so the
-GPU test regenerates them from the seed.  Stored per config: logits [N, ncls] f32, argmax [N], the top-2 margin [N].
+GPU test regenerates them from the seed.  Stored per config: logits [N, ncls] f32, argmax [N], the top-2 margin [N]; for the
+configuration with synchrony matrices also the reference's PLI entries as integer counts [N, 6, C, C] (its sign() decisions).
 
 Usage:  python oracle/make_golden_logits.py
 """
@@ -47,6 +48,13 @@ def main():
         out[name + "/logits"] = lg
         out[name + "/argmax"] = lg.argmax(-1).astype(np.int64)
         out[name + "/margin"] = (top[:, -1] - top[:, -2]).astype(np.float32)
+        if getattr(model, "ibs_matrix_generator", None) is not None and cfg.use_robust_ibs:
+            # the reference's sign() decisions, compactly: PLI = |mean_t sign(dphi_t)| (D:613-630) is |k| / T with integer k, so
+            # round(PLI * T) per (sample, band, channel pair) is exact in uint16.  The GPU test uses it to show that the samples
+            # whose logits differ by more than the plain f32 gate are exactly those where a PLI entry differs.
+            with torch.no_grad():
+                conn = torch.cat([model.ibs_matrix_generator(x1[i:i + CHUNK], x2[i:i + CHUNK]) for i in range(0, N, CHUNK)])
+            out[name + "/pli_counts"] = np.rint(conn[:, :, 1].numpy().astype(np.float64) * 1024).astype(np.uint16)
         print(name, lg.shape, "margin<4e-2:", int((out[name + "/margin"] < 4e-2).sum()), "class counts", np.bincount(lg.argmax(-1)))
     np.savez_compressed(REPO / "tests" / "golden" / "logits512.npz", **out)
 
