@@ -113,83 +113,155 @@ __device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0
 
 // grid (B, nbands, tiles_i * tiles_j): 8x8 channel tile of player 1 x player 2.
 // out conn [B, nbands, 7, C, C] in the reference's feature order [PLV, PLI, wPLI, Coherence, Power_Corr, Phase_Diff, Time_Corr]
+// One time step of a channel is staged into LDS ONCE per tile with everything a pair needs from it -- the band signal a, its phase,
+// cos / sin of the phase and the two z-scores (power, signal) -- so the 64 pairs of the tile cost a handful of multiply-adds per
+// time step: cos(p1 - p2) = c1 c2 + s1 s2, sin(p1 - p2) = s1 c2 - c1 s2 instead of one sincosf per PAIR and time step (the round-2
+// form: 100 M precise sincosf calls per step at C = 8, 1.6 G at the reference's default C = 32, where the launch was 38 % of the
+// whole training step).  A lane owns one time step and walks its wave's 16 pairs (2 channels of player 1 x 8 of player 2) with the
+// ten channel values in registers; per lane the time steps and so the summation order are those of the round-2 kernel, so every
+// feature but PLV (the identity instead of sincosf: 1e-7) is bit-identical to it.
+constexpr int IBS_TC = 256;          // time steps per LDS tile: 2 players x 4 arrays x 8 channels x 256 x 4 B = 64 KB -> two workgroups per CU;
+                                     // one's staging (memory latency) runs beside the other's pair loop (512 steps = 128 KB, one per CU: 4.75 ms at C = 32)
 __global__ __launch_bounds__(256) void ibs_pairs_kernel(const float* __restrict__ xb, const float* __restrict__ phase,
                                                         const float* __restrict__ stats, const cf* __restrict__ spec,
                                                         float* __restrict__ conn, int B, int C, int T, float fs, int nbin,
                                                         BandTable bt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int Tc = min(T, 1024);
-  float* x1 = (float*)smem;       // [8][Tc]
-  float* p1 = x1 + 8 * Tc;
-  float* x2 = p1 + 8 * Tc;
-  float* p2 = x2 + 8 * Tc;
+  const int Tc = min(T, IBS_TC);
+  // [player][array: a, phase, cos, sin][channel 8][Tc]
+  float* const lds = (float*)smem;
   const int b = blockIdx.x, band = blockIdx.y;
   const int tj = (C + 7) / 8;
   const int i0 = (blockIdx.z / tj) * 8, j0 = (blockIdx.z % tj) * 8;
   const int nsig = 2 * B * C;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float acc[16][8];
 #pragma unroll
   for (int a = 0; a < 16; ++a)
 #pragma unroll
     for (int f = 0; f < 8; ++f) acc[a][f] = 0.f;
+  // z-score constants of this wave's channels: player 1 channels 2 wave, 2 wave + 1; player 2 channels 0..7 of the tile
+  float m1[2], r1[2], mp1[2], rp1[2], m2[8], r2[8], mp2[8], rp2[8];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const float* s1 = stats + ((size_t)band * nsig + (size_t)b * C + min(i0 + 2 * wave + u, C - 1)) * 4;
+    m1[u] = s1[0]; r1[u] = s1[1]; mp1[u] = s1[2]; rp1[u] = s1[3];
+  }
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    const float* s2 = stats + ((size_t)band * nsig + (size_t)(b + B) * C + min(j0 + v, C - 1)) * 4;
+    m2[v] = s2[0]; r2[v] = s2[1]; mp2[v] = s2[2]; rp2[v] = s2[3];
+  }
   for (int t0 = 0; t0 < T; t0 += Tc) {
     const int tn = min(Tc, T - t0);
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 8 * tn; idx += blockDim.x) {
-      const int c = idx / tn, t = idx - c * tn;
-      const int ci = min(i0 + c, C - 1), cj = min(j0 + c, C - 1);
-      const size_t s1 = ((size_t)band * nsig + (size_t)b * C + ci) * T + t0 + t;
-      const size_t s2 = ((size_t)band * nsig + (size_t)(b + B) * C + cj) * T + t0 + t;
-      x1[c * Tc + t] = xb[s1]; p1[c * Tc + t] = phase[s1];
-      x2[c * Tc + t] = xb[s2]; p2[c * Tc + t] = phase[s2];
+    // staging: 16-B loads, FOUR (signal, phase) pairs requested before the first is consumed -- with one workgroup per CU the
+    // one-load-per-trip form of round 2 exposed a full memory latency per element and was most of the launch
+    const int tq = tn >> 2;                                       // float4 groups per channel (T is a power of two >= 64)
+    const int nvec = 16 * tq;
+    for (int v0 = threadIdx.x; v0 < nvec; v0 += 4 * 256) {
+      f32x4 av[4], pv[4];
+      int off[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int v = v0 + 256 * u;
+        off[u] = -1;
+        if (v < nvec) {
+          const int pc = v / tq, t = (v - pc * tq) << 2;          // pc = player * 8 + channel of the tile
+          const int pl = pc >> 3, c = pc & 7;
+          const int ch = pl ? min(j0 + c, C - 1) : min(i0 + c, C - 1);
+          const size_t sidx = ((size_t)band * nsig + (size_t)(pl ? b + B : b) * C + ch) * T + t0 + t;
+          av[u] = *(const f32x4*)(xb + sidx);
+          pv[u] = *(const f32x4*)(phase + sidx);
+          off[u] = pl * 4 * 8 * Tc + c * Tc + t;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (off[u] >= 0) {
+          f32x4 cs, sn;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float s_, c_;
+            sincosf(pv[u][e], &s_, &c_);
+            cs[e] = c_; sn[e] = s_;
+          }
+          float* base = lds + off[u];
+          *(f32x4*)base = av[u]; *(f32x4*)(base + 8 * Tc) = pv[u]; *(f32x4*)(base + 16 * Tc) = cs; *(f32x4*)(base + 24 * Tc) = sn;
+        }
+      }
     }
     __syncthreads();
+    const float* const P1 = lds + (2 * wave) * Tc;              // player 1, this wave's first channel
+    const float* const P2 = lds + 4 * 8 * Tc;                   // player 2, channel 0
+    for (int t = lane; t < tn; t += 64) {
+      float a1[2], p1[2], c1[2], s1[2], zq1[2], za1[2], q1[2];
 #pragma unroll
-    for (int a = 0; a < 16; ++a) {
-      const int pr = wave * 16 + a, ii = pr >> 3, jj = pr & 7;
-      const int ci = min(i0 + ii, C - 1), cj = min(j0 + jj, C - 1);
-      const float* s1 = stats + ((size_t)band * nsig + (size_t)b * C + ci) * 4;
-      const float* s2 = stats + ((size_t)band * nsig + (size_t)(b + B) * C + cj) * 4;
-      const float m1 = s1[0], r1 = s1[1], mp1 = s1[2], rp1 = s1[3];
-      const float m2 = s2[0], r2 = s2[1], mp2 = s2[2], rp2 = s2[3];
-      for (int t = lane; t < tn; t += 64) {
-        const float a1 = x1[ii * Tc + t], a2 = x2[jj * Tc + t];
-        const float d = p1[ii * Tc + t] - p2[jj * Tc + t];
-        float sn, cs;
-        sincosf(d, &sn, &cs);
-        const float sg = sgn(d);
-        const float q1 = a1 * a1, q2 = a2 * a2;
-        const float w = (q1 + q2) * 0.5f;
-        acc[a][0] += cs; acc[a][1] += sn; acc[a][2] += sg; acc[a][3] += sg * w; acc[a][4] += w;
-        acc[a][5] += fabsf(d);
-        acc[a][6] += ((q1 - mp1) * rp1) * ((q2 - mp2) * rp2);
-        acc[a][7] += ((a1 - m1) * r1) * ((a2 - m2) * r2);
+      for (int u = 0; u < 2; ++u) {
+        a1[u] = P1[u * Tc + t]; p1[u] = P1[(8 + u) * Tc + t]; c1[u] = P1[(16 + u) * Tc + t]; s1[u] = P1[(24 + u) * Tc + t];
+        q1[u] = a1[u] * a1[u];
+        zq1[u] = (q1[u] - mp1[u]) * rp1[u];
+        za1[u] = (a1[u] - m1[u]) * r1[u];
+      }
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        const float a2 = P2[v * Tc + t], p2 = P2[(8 + v) * Tc + t], c2 = P2[(16 + v) * Tc + t], s2 = P2[(24 + v) * Tc + t];
+        const float q2 = a2 * a2;
+        const float zq2 = (q2 - mp2[v]) * rp2[v], za2 = (a2 - m2[v]) * r2[v];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int a = u * 8 + v;                               // pair (2 wave + u, v) = round-2's pair index wave * 16 + a
+          const float d = p1[u] - p2;
+          const float cs = c1[u] * c2 + s1[u] * s2;
+          const float sn = s1[u] * c2 - c1[u] * s2;
+          const float sg = sgn(d);
+          const float w = (q1[u] + q2) * 0.5f;
+          acc[a][0] += cs; acc[a][1] += sn; acc[a][2] += sg; acc[a][3] += sg * w; acc[a][4] += w;
+          acc[a][5] += fabsf(d);
+          acc[a][6] += zq1[u] * zq2;
+          acc[a][7] += za1[u] * za2;
+        }
       }
     }
   }
   const float invT = 1.0f / (float)T;
   const float df = fs / (float)T;
+  // ---- coherence: mean over the T/2+1 rFFT bins of |X1 X2*|^2 / (|X1|^2 |X2|^2 + 1e-8); only in-band bins are non-zero.
+  //      The in-band spectra of the tile's 16 channels are staged into LDS once (the time-domain tile is finished), and a pair walks
+  //      bins [klo, khi] only.  (Round 2 read both spectra from global memory per pair and bin, behind a band test on all 513 bins:
+  //      16 pairs x 9 trips of exposed load latency per wave, at one wave per SIMD -- most of the launch's 8.8 ms at C = 32.) ----
+  int klo = max(0, (int)ceilf(bt.lo[band] / df)), khi = min(nbin - 1, (int)floorf(bt.hi[band] / df));
+  // the band test of the reference is on f = k * df evaluated in fp32 (D:551): settle the two edges with that very predicate
+  while (klo > 0 && (float)(klo - 1) * df >= bt.lo[band]) --klo;
+  while (klo < nbin && (float)klo * df < bt.lo[band]) ++klo;
+  while (khi + 1 < nbin && (float)(khi + 1) * df <= bt.hi[band]) ++khi;
+  while (khi >= 0 && (float)khi * df > bt.hi[band]) --khi;
+  const int nin = max(0, khi - klo + 1);                 // <= 179 bins (0.5 .. 45 Hz at df = 0.25 Hz) x 16 channels x 8 B = 23 KB
+  __syncthreads();
+  cf* const sp = (cf*)smem;                              // [player * 8 + channel][nin]
+  for (int idx = threadIdx.x; idx < 16 * nin; idx += blockDim.x) {
+    const int pc = idx / nin, k = idx - pc * nin;
+    const int pl = pc >> 3, c = pc & 7;
+    const int ch = pl ? min(j0 + c, C - 1) : min(i0 + c, C - 1);
+    sp[idx] = spec[((size_t)(pl ? b + B : b) * C + ch) * nbin + klo + k];
+  }
+  __syncthreads();
 #pragma unroll
   for (int a = 0; a < 16; ++a) {
     const int pr = wave * 16 + a, ii = pr >> 3, jj = pr & 7;
     float v[8];
 #pragma unroll
     for (int f = 0; f < 8; ++f) v[f] = wave_sum(acc[a][f]);
-    // coherence: mean over the T/2+1 rFFT bins of |X1 X2*|^2 / (|X1|^2 |X2|^2 + 1e-8); only in-band bins are non-zero
     float coh = 0.f;
-    const int ci = min(i0 + ii, C - 1), cj = min(j0 + jj, C - 1);
-    const cf* f1 = spec + ((size_t)b * C + ci) * nbin;
-    const cf* f2 = spec + ((size_t)(b + B) * C + cj) * nbin;
-    for (int k = lane; k < nbin; k += 64) {
-      const float f = (float)k * df;
-      if (f >= bt.lo[band] && f <= bt.hi[band]) {
-        const cf u = f1[k], w = f2[k];
-        const cf xy = cmul(u, make_float2(w.x, -w.y));
-        const float num = xy.x * xy.x + xy.y * xy.y;
-        const float pxx = u.x * u.x + u.y * u.y, pyy = w.x * w.x + w.y * w.y;
-        coh += num / (pxx * pyy + 1e-8f);
-      }
+    const cf* f1 = sp + ii * nin;
+    const cf* f2 = sp + (8 + jj) * nin;
+    for (int k = lane; k < nin; k += 64) {
+      const cf u = f1[k], w = f2[k];
+      const cf xy = cmul(u, make_float2(w.x, -w.y));
+      const float num = xy.x * xy.x + xy.y * xy.y;
+      const float pxx = u.x * u.x + u.y * u.y, pyy = w.x * w.x + w.y * w.y;
+      coh += num / (pxx * pyy + 1e-8f);
     }
     coh = wave_sum(coh) / (float)(T / 2 + 1);
     if (lane == 0 && i0 + ii < C && j0 + jj < C) {
@@ -443,11 +515,11 @@ extern "C" int eg_ibs_pairs(const float* xb, const float* phase, const float* st
   EG_CHECK(B > 0 && C > 0 && T > 0, "eg_ibs_pairs: bad shape");
   BandTable bt;
   EG_CHECK(fill_bands(bt, band_lo, band_hi, nbands) == 0, "eg_ibs_pairs: nbands=%d", nbands);
-  const int Tc = T < 1024 ? T : 1024;
-  const int lds = 4 * 8 * Tc * 4;
+  const int Tc = T < IBS_TC ? T : IBS_TC;
+  const int lds = 2 * 4 * 8 * Tc * 4;            // two players x (a, phase, cos, sin) x 8 channels x Tc
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)ibs_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 8 * 1024 * 4);
+    (void)hipFuncSetAttribute((const void*)ibs_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 8 * IBS_TC * 4);
     attr = true;
   }
   const int tiles = ((C + 7) / 8) * ((C + 7) / 8);
