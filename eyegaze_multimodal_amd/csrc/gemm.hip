@@ -679,11 +679,19 @@ __global__ __launch_bounds__(256) void reduce_table_kernel(const eg_reduce_entry
 
 // out[i] = sum_s partial[s*sstride + i].  256 threads = 8 float4 columns x 32 split lanes, so short outputs
 // (bias / LayerNorm-gain gradients, n ~ 256) still spread their `splits` loads over many lanes.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                              long long n, int splits, long long sstride, int accumulate) {
+// group > 0 (first stage of a long reduction, grid.y groups): block (x, g) sums splits [g * group, (g + 1) * group) and leaves the
+// sum IN PLACE in the group's first row; a second launch then sums those rows.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* partial, float* out,
+                                                              long long n, int splits, long long sstride, int accumulate, int group) {
   __shared__ f32x4 red[32][8];
   const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
   const long long i4 = ((long long)blockIdx.x * 8 + tx) * 4;
+  if (group > 0) {
+    const int k0 = blockIdx.y * group;
+    partial += (size_t)k0 * sstride;
+    out = const_cast<float*>(partial);
+    splits = min(group, splits - k0);
+  }
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i4 + 4 <= n) {
     for (int k = ty; k < splits; k += 32) s += *(const f32x4*)(partial + (size_t)k * sstride + i4);
@@ -902,14 +910,28 @@ extern "C" int eg_gemm_tn(const eg_gemm_tn_desc* d, void* stream) {
   return d->dtype == EG_BF16 ? launch_gemm_tn<bf16_t>(d, s) : d->dtype == EG_F16 ? launch_gemm_tn<f16_t>(d, s) : launch_gemm_tn<float>(d, s);
 }
 
-extern "C" int eg_reduce_partials(const float* partial, float* out, int64_t n, int splits, int64_t split_stride,
+extern "C" int eg_reduce_partials(float* partial, float* out, int64_t n, int splits, int64_t split_stride,
                                   int accumulate, void* stream) {
   EG_CHECK(partial && out && n > 0 && splits > 0 && split_stride >= n, "eg_reduce_partials: bad arguments");
   EG_CHECK(((uintptr_t)partial | (uintptr_t)out) % 16 == 0 && split_stride % 4 == 0,
            "eg_reduce_partials: 16-B alignment (split_stride %% 4 == 0)");
   const long long ncol = (n + 3) / 4;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((ncol + 7) / 8)), dim3(256), 0,
-                     (hipStream_t)stream, partial, out, (long long)n, splits, (long long)split_stride, accumulate);
+  const unsigned gx = (unsigned)((ncol + 7) / 8);
+  // A long reduction over a short vector (the spectrogram conv-1 gradient: 16 384 per-image partials of 320 floats at C = 32) left
+  // one to nine workgroups walking thousands of rows each: 175 us of exposed load latency per call.  Two stages instead: 64 groups
+  // of rows are summed in parallel, IN PLACE into each group's first row (the partial buffer is scratch), then those 64 rows.
+  if (splits >= 2048 && gx <= 64) {
+    const int groups = 64, group = (splits + groups - 1) / groups;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, (unsigned)((splits + group - 1) / group)), dim3(256), 0, (hipStream_t)stream,
+                       partial, out, (long long)n, splits, (long long)split_stride, 0, group);
+    EG_LAUNCH_CHECK("reduce_partials (stage 1)");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, partial, out, (long long)n,
+                       (splits + group - 1) / group, (long long)split_stride * group, accumulate, 0);
+    EG_LAUNCH_CHECK("reduce_partials");
+    return 0;
+  }
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx), dim3(256), 0,
+                     (hipStream_t)stream, partial, out, (long long)n, splits, (long long)split_stride, accumulate, 0);
   EG_LAUNCH_CHECK("reduce_partials");
   return 0;
 }

@@ -360,22 +360,26 @@ __global__ __launch_bounds__(256) void ibs_scalar_kernel(const float* __restrict
   }
 }
 
-// STFT log-magnitude: x [nsig, T] -> img [nsig, F, nfr] fp32; one block = 4 frames x 64 bins (n_fft = 128)
-__global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restrict__ x, const float* __restrict__ window,
-                                                          float* __restrict__ img, int T, int n_fft, int hop, int F,
-                                                          int nfr) {
+// STFT log-magnitude: x [nsig, T] -> img [nsig, F, nfr] fp32; one 64-thread block = 4 frames x up to 64 bins (n_fft = 128).
+// A lane owns one frequency bin and keeps the four frames' sums in registers: per sample index n it reads its twiddle pair once
+// and the four frame values as ONE broadcast 16-B read, for 8 multiply-adds (round 2: a wave per frame, 3 LDS reads per 2
+// multiply-adds, LDS-bound at 359 us per launch at C = 32).  Same n-ascending fmaf chains per (frame, bin): bit-identical results.
+__global__ __launch_bounds__(64) void stft_logmag_kernel(const float* __restrict__ x, const float* __restrict__ window,
+                                                         float* __restrict__ img, int T, int n_fft, int hop, int F,
+                                                         int nfr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* fr = (float*)smem;          // [4][n_fft] windowed frames
+  float* fr = (float*)smem;          // [n_fft][4] windowed frames, frame-interleaved
   float* ct = fr + 4 * n_fft;        // [n_fft] cos table
   float* stb = ct + n_fft;           // [n_fft] sin table
   const int sig = blockIdx.y, f0 = blockIdx.x * 4;
-  for (int i = threadIdx.x; i < n_fft; i += blockDim.x) {
+  for (int i = threadIdx.x; i < n_fft; i += 64) {
     float sn, cs;
     sincospif(2.0f * (float)i / (float)n_fft, &sn, &cs);
     ct[i] = cs; stb[i] = sn;
   }
-  for (int i = threadIdx.x; i < 4 * n_fft; i += blockDim.x) {
-    const int f = f0 + i / n_fft, n = i % n_fft;
+  for (int i = threadIdx.x; i < 4 * n_fft; i += 64) {
+    const int fl = i / n_fft, n = i % n_fft;
+    const int f = f0 + fl;
     float v = 0.f;
     if (f < nfr) {
       int t = f * hop + n - n_fft / 2;       // center=True, reflect padding
@@ -383,19 +387,24 @@ __global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restric
       if (t >= T) t = 2 * (T - 1) - t;
       v = x[(size_t)sig * T + t] * window[n];
     }
-    fr[i] = v;
+    fr[n * 4 + fl] = v;
   }
   __syncthreads();
-  const int fl = threadIdx.x / 64, k = threadIdx.x % 64;
-  const int f = f0 + fl;
-  for (int kk = k; kk < F; kk += 64) {
-    float re = 0.f, im = 0.f;
+  for (int kk = threadIdx.x; kk < F; kk += 64) {
+    float re[4] = {0.f, 0.f, 0.f, 0.f}, im[4] = {0.f, 0.f, 0.f, 0.f};
     for (int n = 0; n < n_fft; ++n) {
       const int idx = (kk * n) & (n_fft - 1);
-      re = fmaf(fr[fl * n_fft + n], ct[idx], re);
-      im = fmaf(fr[fl * n_fft + n], -stb[idx], im);
+      const float c = ct[idx], ns = -stb[idx];
+      const f32x4 v = *(const f32x4*)(fr + 4 * n);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        re[q] = fmaf(v[q], c, re[q]);
+        im[q] = fmaf(v[q], ns, im[q]);
+      }
     }
-    if (f < nfr) img[((size_t)sig * F + kk) * nfr + f] = logf(sqrtf(re * re + im * im) + 1e-8f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (f0 + q < nfr) img[((size_t)sig * F + kk) * nfr + f0 + q] = logf(sqrtf(re[q] * re[q] + im[q] * im[q]) + 1e-8f);
   }
 }
 
@@ -549,7 +558,7 @@ extern "C" int eg_stft_logmag(const float* x, const float* window, float* img, i
   EG_CHECK(nsig > 0 && is_pow2(n_fft) && n_fft <= 1024 && hop > 0 && F > 0 && F <= n_fft / 2 + 1 && T > n_fft / 2,
            "eg_stft_logmag: bad shape T=%d n_fft=%d hop=%d F=%d", T, n_fft, hop, F);
   const int nfr = 1 + T / hop;
-  hipLaunchKernelGGL(stft_logmag_kernel, dim3((nfr + 3) / 4, nsig), dim3(256), 6 * n_fft * 4, (hipStream_t)stream, x, window,
+  hipLaunchKernelGGL(stft_logmag_kernel, dim3((nfr + 3) / 4, nsig), dim3(64), 6 * n_fft * 4, (hipStream_t)stream, x, window,
                      img, T, n_fft, hop, F, nfr);
   EG_LAUNCH_CHECK("stft_logmag");
   return 0;

@@ -257,8 +257,9 @@ int eg_gemm_tn_grouped(const eg_tn_problem* probs, int nprob, int total_blocks, 
  * (N/256) * (K/256) * splits blocks per problem): half the operand traffic per output, bit-identical partial slabs. */
 int eg_gemm_tn_grouped256(const eg_tn_problem* probs, int nprob, int total_blocks, int M, int splits, int dtype, void* stream);
 int eg_reduce_table(const eg_reduce_entry* table, int nentries, int total_blocks, void* stream);
-/* out[i] = (accumulate ? out[i] : 0) + sum_s partial[s*split_stride + i]; used for dW, db, LayerNorm dgamma/dbeta */
-int eg_reduce_partials(const float* partial, float* out, int64_t n, int splits, int64_t split_stride, int accumulate,
+/* out[i] = (accumulate ? out[i] : 0) + sum_s partial[s*split_stride + i]; used for dW, db, LayerNorm dgamma/dbeta.  `partial` is
+ * scratch: with splits >= 2048 over a short vector the sum runs in two stages and stage 1 overwrites rows of `partial`. */
+int eg_reduce_partials(float* partial, float* out, int64_t n, int splits, int64_t split_stride, int accumulate,
                        void* stream);
 /* conv weight gradient back to the parameter layout: dW[n][c][tap] = sum_s partial[s][n][tap*Cp + c] */
 int eg_unpack_conv_wgrad(const float* partial, float* dW, int splits, int N, int Cin, int k, int Cp, int Kp,
