@@ -137,6 +137,7 @@ SIGNATURES = {
     "eg_aux_infonce": [_P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P],
     "eg_aux_supcon": [_P, _P, _F, _P, _P, _P, _I, _I, _P],
     "eg_fuzzy_gate_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P],
+    "eg_fusion_loop_loss": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _F, _P, _P],
     "eg_fuzzy_gate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P],
     "eg_ibs_analytic": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P, _P, _I, _P],
     "eg_ibs_pairs": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _I, _P],

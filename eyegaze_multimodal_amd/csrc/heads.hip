@@ -593,6 +593,83 @@ extern "C" int eg_rows_gather_gate(const void* src, const void* gate, void* dst,
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The loss of the multimodal logit-fusion step and its gradients on the [B, K] logits, in ONE single-workgroup launch
+// (train_multimodal_fuzzy_fusion.py:436-460): L = CE(fused) + l_img CE(z_img / T_img) + l_eeg CE(z_eeg / T_eeg) + l_reg R(T),
+// temperatures DETACHED in the auxiliary terms (fuzzy_gating_fusion.py:334), R = relu(T - t_max) + relu(t_min - T) over both
+// temperatures (:392-419), T = softplus(tau) + eps_temp.  As torch autograd on 2 x [B, 3] tensors this was ~70 tiny launches with
+// 10-40 us of host time between them: 0.8 ms of idle GPU per step of BASELINE configs[4].
+//   losses[5] = total, ce, aux_img, aux_eeg, reg
+//   dfused    = dL/dfused  (feed eg_fuzzy_gate_bwd);  daux_img / daux_eeg = the auxiliary terms' direct gradients on the logits
+//   dtau[2]   = l_reg dR/dtau_img, l_reg dR/dtau_eeg
+// every gradient is multiplied by the loss scale of `state` when its scaler is on (GradScaler.scale(loss).backward(), :462).
+// Summation over the batch in a fixed order (deterministic).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fusion_loop_loss_kernel(const float* __restrict__ fused, const float* __restrict__ zi,
+                                                               const float* __restrict__ ze, const long long* __restrict__ labels,
+                                                               const float* __restrict__ prm, float* __restrict__ losses,
+                                                               float* __restrict__ dfused, float* __restrict__ dai,
+                                                               float* __restrict__ dae, float* __restrict__ dtau, int B, int K,
+                                                               int mode, float eps_temp, float l_img, float l_eeg, float l_reg,
+                                                               float t_min, float t_max, const eg_step_state* st) {
+  __shared__ float red[3][256];
+  const float scale = (st && st->scaler_on) ? st->loss_scale : 1.0f;
+  float ti = 1.f, te = 1.f;
+  if (mode == 0 || mode == 2) { ti = softplus_f(prm[0]) + eps_temp; te = softplus_f(prm[1]) + eps_temp; }
+  const float invB = 1.0f / (float)B;
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const int y = (int)labels[b];
+    const float* rows[3] = {fused + (size_t)b * K, zi + (size_t)b * K, ze + (size_t)b * K};
+    float* outs[3] = {dfused + (size_t)b * K, dai + (size_t)b * K, dae + (size_t)b * K};
+    const float tdiv[3] = {1.f, ti, te};
+    const float wgt[3] = {1.f, l_img, l_eeg};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      float z[16], mx = -INFINITY, se = 0.f;
+      for (int c = 0; c < K; ++c) { z[c] = rows[q][c] / tdiv[q]; mx = fmaxf(mx, z[c]); }
+      for (int c = 0; c < K; ++c) se += expf(z[c] - mx);
+      const float lse = mx + logf(se);
+      acc[q] += lse - z[y];                                    // -log softmax(z)[y]
+      const float g = wgt[q] * invB * scale / tdiv[q];
+      for (int c = 0; c < K; ++c) outs[q][c] = (expf(z[c] - lse) - (c == y ? 1.f : 0.f)) * g;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) red[q][threadIdx.x] = acc[q];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot[3] = {0.f, 0.f, 0.f};
+    for (int q = 0; q < 3; ++q) {
+      for (int i = 0; i < 256; ++i) tot[q] += red[q][i];
+      tot[q] *= invB;
+    }
+    // the regulariser always reads the learnable temperatures (fuzzy_gating_fusion.py:392-419), whatever the mode
+    const float Ti = softplus_f(prm[0]) + eps_temp, Te = softplus_f(prm[1]) + eps_temp;
+    const float reg = fmaxf(Ti - t_max, 0.f) + fmaxf(t_min - Ti, 0.f) + fmaxf(Te - t_max, 0.f) + fmaxf(t_min - Te, 0.f);
+    auto sig = [](float x) { return 1.0f / (1.0f + expf(-x)); };
+    dtau[0] = l_reg * scale * ((Ti > t_max ? 1.f : 0.f) - (Ti < t_min ? 1.f : 0.f)) * sig(prm[0]);
+    dtau[1] = l_reg * scale * ((Te > t_max ? 1.f : 0.f) - (Te < t_min ? 1.f : 0.f)) * sig(prm[1]);
+    losses[1] = tot[0]; losses[2] = tot[1]; losses[3] = tot[2]; losses[4] = reg;
+    losses[0] = tot[0] + l_img * tot[1] + l_eeg * tot[2] + l_reg * reg;
+  }
+}
+
+extern "C" int eg_fusion_loop_loss(const float* fused, const float* z_img, const float* z_eeg, const int64_t* labels,
+                                   const float* params, float* losses, float* dfused, float* daux_img, float* daux_eeg,
+                                   float* dtau, int B, int K, int mode, float eps_temp, float lambda_aux_img,
+                                   float lambda_aux_eeg, float lambda_reg, float t_min, float t_max, const eg_step_state* state,
+                                   void* stream) {
+  EG_CHECK(fused && z_img && z_eeg && labels && params && losses && dfused && daux_img && daux_eeg && dtau,
+           "eg_fusion_loop_loss: null pointer");
+  EG_CHECK(B > 0 && K > 1 && K <= 16 && mode >= 0 && mode <= 3, "eg_fusion_loop_loss: bad shape / mode");
+  hipLaunchKernelGGL(fusion_loop_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, fused, z_img, z_eeg,
+                     (const long long*)labels, params, losses, dfused, daux_img, daux_eeg, dtau, B, K, mode, eps_temp,
+                     lambda_aux_img, lambda_aux_eeg, lambda_reg, t_min, t_max, state);
+  EG_LAUNCH_CHECK("fusion_loop_loss");
+  return 0;
+}
+
 extern "C" int eg_fuzzy_gate_bwd(const float* z_img, const float* z_eeg, const float* params, const float* dfused,
                                  const float* dalpha, float* dz_img, float* dz_eeg, float* partial, int B, int K, int mode,
                                  float eps_temp, float eps_log, float eps_div, void* stream) {

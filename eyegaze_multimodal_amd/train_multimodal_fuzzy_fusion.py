@@ -26,6 +26,7 @@ collective before any AdamW kernel reads it, so an fp16 overflow on ONE rank ski
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -83,6 +84,15 @@ class MultimodalTrainer:
         self.state = {}        # per parameter set: exp_avg, exp_avg_sq
         self.sqpart = None
         self.eng = None
+        # fusion + losses + their gradients on the [B, K] logits as four HIP launches (eg_fuzzy_gate_fwd, eg_fusion_loop_loss,
+        # eg_fuzzy_gate_bwd, a reduce) instead of a torch autograd graph of ~70 tiny kernels (0.8 ms of idle GPU per step at B = 256)
+        self.fused_loss = os.environ.get("EYEGAZE_MM_FUSED_LOSS", "1") != "0"
+        fz = model.fusion
+        names = ["tau_img", "tau_eeg", "c_unreliable_img", "c_unreliable_eeg", "log_sigma_reliable_img", "log_sigma_reliable_eeg",
+                 "log_sigma_unreliable_img", "log_sigma_unreliable_eeg"]       # FuzzyGatingFusion._packed's order
+        idx = [self.fus.offsets[n] for n in names] + [self.fus.offsets["beta"] + i for i in range(4)]
+        self._prm_idx = torch.tensor(idx, dtype=torch.int64, device=self.device)
+        self._lw = {}          # per (B, K): work tensors of the fused loss path
 
     # ------------------------------------------------------------------------------------------
     def _engines(self, B, T, F_, W_):
@@ -127,6 +137,8 @@ class MultimodalTrainer:
         t = self.step_no + 1
         eeg.set_state(seed=self.seed * 7919 + t, lr=lr, step=t, beta1=self.betas[0], beta2=self.betas[1],
                       grad_scale=(red.grad_scale if red else 1.0))
+        if self.fused_loss:
+            return self._train_step_fused(m, eeg, img, red, img1, img2, eeg1, eeg2, labels, dropout)
         # ---- forward of both encoders (HIP) ----
         z_img = img.forward(img1.contiguous().float(), img2.contiguous().float(), train=dropout).detach().clone().requires_grad_(True)
         eeg.forward(eeg1.contiguous().float(), eeg2.contiguous().float(), labels, train=dropout)
@@ -166,6 +178,55 @@ class MultimodalTrainer:
         return {"loss": loss.detach(), "loss_ce": loss_ce.detach(), "loss_aux_img": loss_aux_img.detach(),
                 "loss_aux_eeg": loss_aux_eeg.detach(), "loss_reg": loss_reg.detach(), "alpha": alpha.detach(),
                 "fused_logits": fused.detach()}
+
+    def _train_step_fused(self, m, eeg, img, red, img1, img2, eeg1, eeg2, labels, dropout):
+        """The same step with the `[B, K]` part -- fusion, the four loss terms and every gradient on the logits and the 12 fusion
+        scalars -- as HIP launches (M:436-462); equal to the autograd form to fp32 rounding (tests/test_gpu_multimodal.py)."""
+        fz, fus, dev = m.fusion, self.fus, self.device
+        st = eeg._cur_stream()
+        z_img = img.forward(img1.contiguous().float(), img2.contiguous().float(), train=dropout)
+        eeg.forward(eeg1.contiguous().float(), eeg2.contiguous().float(), labels, train=dropout)
+        z_eeg = eeg.a["logits"]
+        B, K = z_eeg.shape
+        w = self._lw.get((B, K))
+        if w is None:
+            f32 = dict(device=dev, dtype=torch.float32)
+            w = dict(fused=torch.empty(B, K, **f32), alpha=torch.empty(B, **f32), losses=torch.zeros(5, **f32),
+                     dfused=torch.empty(B, K, **f32), dai=torch.empty(B, K, **f32), dae=torch.empty(B, K, **f32),
+                     dzi=torch.empty(B, K, **f32), dze=torch.empty(B, K, **f32), dtau=torch.zeros(2, **f32),
+                     part=torch.empty((B + 127) // 128, 12, **f32), dprm=torch.zeros(12, **f32))
+            self._lw[(B, K)] = w
+        mode = fz.VALID_MODES.index(fz.mode)
+        prm = fus.flat.index_select(0, self._prm_idx)
+        lab = labels.to(torch.int64).contiguous()
+        li, le, lr_ = self.lams
+        call("eg_fuzzy_gate_fwd", ptr(z_img), ptr(z_eeg), ptr(prm), ptr(w["fused"]), ptr(w["alpha"]), B, K, mode, fz.eps_temp,
+             fz.eps_log, fz.eps_div, st)
+        call("eg_fusion_loop_loss", ptr(w["fused"]), ptr(z_img), ptr(z_eeg), ptr(lab), ptr(prm), ptr(w["losses"]), ptr(w["dfused"]),
+             ptr(w["dai"]), ptr(w["dae"]), ptr(w["dtau"]), B, K, mode, fz.eps_temp, li, le, lr_, self.treg[0], self.treg[1],
+             eeg.st_ptr if eeg.scaler_on else 0, st)
+        call("eg_fuzzy_gate_bwd", ptr(z_img), ptr(z_eeg), ptr(prm), ptr(w["dfused"]), 0, ptr(w["dzi"]), ptr(w["dze"]), ptr(w["part"]),
+             B, K, mode, fz.eps_temp, fz.eps_log, fz.eps_div, st)
+        call("eg_reduce_partials", ptr(w["part"]), ptr(w["dprm"]), 12, w["part"].shape[0], 12, 0, st)
+        w["dzi"] += w["dai"]
+        w["dze"] += w["dae"]
+        w["dprm"][:2] += w["dtau"]
+        fus.grad.index_copy_(0, self._prm_idx, w["dprm"])        # (the flat buffer's 16-B padding slots stay zero)
+        if red:
+            red.on_fusion()
+        if not m.freeze_gaze:
+            img.backward(w["dzi"])
+            if red:
+                red.on_gaze()
+        if not m.freeze_eeg:
+            eeg.backward(glogits=w["dze"], prescaled=True, on_segment=(red.on_eeg_segment if red else None))
+        if red:
+            red.finish()
+        self._optimizer_step(eeg, img)
+        self.step_no += 1
+        ls = w["losses"].clone()
+        return {"loss": ls[0], "loss_ce": ls[1], "loss_aux_img": ls[2], "loss_aux_eeg": ls[3], "loss_reg": ls[4],
+                "alpha": w["alpha"].clone(), "fused_logits": w["fused"].clone()}
 
     def _optimizer_step(self, eeg, img):
         m, st = self.model, eeg._cur_stream()

@@ -345,6 +345,16 @@ int eg_aux_supcon(const float* ibs, const int64_t* labels, float temperature, fl
  * eg_fuzzy_gate_bwd: what autograd computes through that forward — dz_img, dz_eeg [B,K] and the 12 parameter gradients as
  *   per-workgroup partials partial[ceil(B/128)][12] (sum them in block order with eg_reduce_partials), from dfused [B,K] and
  *   dalpha [B] (or NULL).  torch.clamp semantics: the gradient passes where min <= x <= max. */
+/* The loss of the multimodal logit-fusion step and its gradients on the [B, K] logits in one launch --
+ * 4_Experiments/scripts/train_multimodal_fuzzy_fusion.py:436-460: total = CE(fused) + lambda_aux_img CE(z_img / T_img) +
+ * lambda_aux_eeg CE(z_eeg / T_eeg) + lambda_reg R(T), temperatures detached in the auxiliary terms (fuzzy_gating_fusion.py:334),
+ * R the temperature regulariser (:392-419).  losses[5] = total, ce, aux_img, aux_eeg, reg; dfused = d total / d fused (the upstream
+ * gradient of eg_fuzzy_gate_bwd); daux_img / daux_eeg = the auxiliary terms' direct gradients on z_img / z_eeg; dtau[2] = the
+ * regulariser's gradients on tau_img, tau_eeg.  Every gradient is multiplied by state->loss_scale when the scaler is on. */
+int eg_fusion_loop_loss(const float* fused, const float* z_img, const float* z_eeg, const int64_t* labels, const float* params,
+                        float* losses, float* dfused, float* daux_img, float* daux_eeg, float* dtau, int B, int K, int mode,
+                        float eps_temp, float lambda_aux_img, float lambda_aux_eeg, float lambda_reg, float t_min, float t_max,
+                        const eg_step_state* state, void* stream);
 int eg_fuzzy_gate_fwd(const float* z_img, const float* z_eeg, const float* params, float* fused, float* alpha, int B,
                       int K, int mode, float eps_temp, float eps_log, float eps_div, void* stream);
 int eg_fuzzy_gate_bwd(const float* z_img, const float* z_eeg, const float* params, const float* dfused, const float* dalpha,

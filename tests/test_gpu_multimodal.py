@@ -173,3 +173,39 @@ def test_f32_loop_matches_the_reference_loop_fixture():
         assert abs(float(delta.norm()) - dn) <= 2e-2 * dn + 1e-6, (n, float(delta.norm()), dn)
         if n.startswith("fusion."):
             np.testing.assert_allclose(final[n].detach().cpu().double().numpy(), z["final/" + n], rtol=0, atol=2e-4, err_msg=n)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "fp16"])
+@pytest.mark.parametrize("mode", ["full", "no_temperature", "no_fuzzification", "fixed_weights"])
+def test_fused_loss_path_equals_the_autograd_path(dtype, mode, monkeypatch):
+    """eg_fusion_loop_loss + the gate kernels (default) against the torch autograd graph they replace (EYEGAZE_MM_FUSED_LOSS=0):
+    same losses, alpha, fused logits and -- after three steps with dropout off -- the same parameters of all three sets."""
+    res = {}
+    B, F_, W_ = 8, 64, 16
+    img1, img2, x1, x2, y = synth_multimodal(B, 8, 1024, F_, W_, 3, seed=5)
+    d = lambda t_: t_.to(DEV)
+    for flag in ("1", "0"):
+        monkeypatch.setenv("EYEGAZE_MM_FUSED_LOSS", flag)
+        torch.manual_seed(3)
+        eeg = DualEEGTransformer(**KW, compute_dtype=dtype)
+        gaze = GazeCNNEncoder(num_classes=3, d_model=64, compute_dtype=dtype)
+        fusion = FuzzyGatingFusion(num_classes=3, mode=mode)
+        with torch.no_grad():                      # temperatures outside [0.5, 5]: the regulariser and its gradient are active
+            fusion.tau_img.fill_(6.0)
+            fusion.tau_eeg.fill_(-2.0)
+        model = MultimodalFusionModel(gaze, eeg, fusion)
+        tr = MultimodalTrainer(model, DEV, encoder_lr=2e-4, fusion_lr=2e-3, warmup_steps=1, total_steps=10)
+        assert tr.fused_loss == (flag == "1")
+        outs = [tr.train_step(d(img1), d(img2), d(x1), d(x2), d(y), dropout=False) for _ in range(3)]
+        torch.cuda.synchronize()
+        res[flag] = (outs, [f.clone() for f in (eeg._flat.flat, gaze._flat.flat, tr.fus.flat)],
+                     model.eeg_encoder.engine(B, 1024, DEV).read_state())
+    for a, b in zip(res["1"][0], res["0"][0]):
+        for k in ("loss", "loss_ce", "loss_aux_img", "loss_aux_eeg", "loss_reg"):
+            assert abs(float(a[k]) - float(b[k])) < (2e-6 if dtype == "f32" else 2e-3) * max(1.0, abs(float(b[k]))), k
+        np.testing.assert_allclose(a["alpha"].cpu().numpy(), b["alpha"].cpu().numpy(), atol=1e-6 if dtype == "f32" else 2e-3)
+    assert float(res["1"][0][0]["loss_reg"]) > 0.5            # the regulariser really was active
+    for fa, fb in zip(res["1"][1], res["0"][1]):
+        num, den = float((fa - fb).double().norm()), float(fb.double().norm())
+        assert num <= (2e-6 if dtype == "f32" else 2e-3) * den, (num, den)
+    assert res["1"][2].opt_steps == res["0"][2].opt_steps
