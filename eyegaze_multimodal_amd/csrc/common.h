@@ -47,7 +47,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(bf16_t, b);
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// both halves in ONE v_cvt_pk_bf16_f32 (written as two scalar converts the compiler emits one convert per value plus a shift and an or)
+typedef __attribute__((ext_vector_type(2))) __bf16 eg_bf16x2;
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){lo, hi}, eg_bf16x2));
+}
 __device__ __forceinline__ float h2f(uint16_t bits) { return (float)__builtin_bit_cast(_Float16, bits); }
 __device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }   // round-to-nearest-even
 __device__ __forceinline__ uint32_t pack2h(float lo, float hi) {

@@ -63,7 +63,9 @@ template <typename T> __device__ __forceinline__ u32x2 f_pack4(const float v[4])
   return o;
 }
 
-template <typename T, int GATE, int BOUT>
+// EPI selects epilogue 1's bias / ReLU at compile time: 3 = bias + ReLU (the forward pass), 0 = neither (the backward pass),
+// 4 = as the descriptor says at run time (a per-value select on the flag -- 80 extra vector instructions per chunk).
+template <typename T, int GATE, int BOUT, int EPI>
 __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   typedef typename H16<T>::frag frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -91,19 +93,20 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   // ---- weight fragment streams (global -> registers): the weights arrive in FRAGMENT ORDER (eg_pack_table modes 3-6), so a
   //      fragment load is one contiguous 1-KB read per wave.  (Row-major weights cost 64 L1 tag look-ups per load -- 16 rows x
   //      64 B per quarter wave -- and made the launch tag-rate-bound: 98 us against 72 us for the two launches it replaces.) ----
-  const T* const w1p = p.W1 + (size_t)wn * (8 * 2 * 512) + lane * 8;      // + c * (4*8*2*512) + (s * 2 + j) * 512
-  const T* const w2p = p.W2 + (size_t)wn * (4 * 4 * 512) + lane * 8;      // + c * (4*4*4*512) + (s * 4 + j) * 512
+  const char* const w1u = (const char*)(p.W1 + (size_t)wn * (8 * 2 * 512));      // + c * (4*8*2*512) + (s * 2 + j) * 512   [elements]
+  const char* const w2u = (const char*)(p.W2 + (size_t)wn * (4 * 4 * 512));      // + c * (4*4*4*512) + (s * 4 + j) * 512
+  const uint32_t wl = (uint32_t)lane * 16u;                                      // wave-uniform base + 32-bit lane offset: saddr loads
   // Rolling rings, four (W1) / two (W2) k-steps ahead of their MFMAs and running on across chunk boundaries.  (Requesting a
   // whole chunk's fragments one phase ahead -- 16 + 16 live fragments -- was built: 67-88 spilled registers; the 256-register
   // budget of two waves per SIMD is spent on the 5 x 4 + 5 x 2 accumulator tiles.)
   frag w1r[4][2], w2r[2][4];
   auto req_w1 = [&](int c, int s, int slot) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) w1r[slot][j] = *(const frag*)(w1p + (size_t)c * (4 * 8 * 2 * 512) + (s * 2 + j) * 512);
+    for (int j = 0; j < 2; ++j) w1r[slot][j] = *(const frag*)(w1u + ((size_t)c * (4 * 8 * 2 * 512) + (s * 2 + j) * 512) * 2 + wl);
   };
   auto req_w2 = [&](int c, int s, int slot) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w2r[slot][j] = *(const frag*)(w2p + (size_t)c * (4 * 4 * 4 * 512) + (s * 4 + j) * 512);
+    for (int j = 0; j < 4; ++j) w2r[slot][j] = *(const frag*)(w2u + ((size_t)c * (4 * 4 * 4 * 512) + (s * 4 + j) * 512) * 2 + wl);
   };
 #pragma unroll
   for (int s = 0; s < 4; ++s) req_w1(0, s, s);
@@ -147,6 +150,16 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   }
   const int rbase = l15;                                     // row of tile i within the workgroup: rbase + 16 i
   const int sw7 = l15 & 7;
+  // epilogue-1 lane constants: byte offset of this lane's 8-B slot (row l15, hidden column 32 wn + 16 j + 4 g4 of the chunk) in the
+  // swizzled chunk image -- tile row i adds the immediate 4096 i -- and the dropout PAIR index of (row m0 + l15, column 32 wn + 4 g4)
+  int ha[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int hcol = 32 * wn + 16 * j + 4 * g4;
+    ha[j] = l15 * 256 + (((hcol >> 3) ^ sw7) << 4) + ((hcol & 4) << 1);
+  }
+  const uint32_t pair0 = ((uint32_t)(m0 + l15) * (uint32_t)p.F + (uint32_t)(32 * wn + 4 * g4)) >> 1;
+  const uint32_t pairF = 8u * (uint32_t)p.F;                 // 16 rows further
 
   for (int c = 0; c < nch; ++c) {
     char* const hc = hb + (c & 1) * F_HT;
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) b1[j][q] = 0.f;
-      if (p.bias1) load4(p.bias1 + f0 + 16 * j, b1[j]);
+      if (EPI == 3 || (EPI == 4 && p.bias1)) load4(p.bias1 + f0 + 16 * j, b1[j]);
     }
 
     u32x2 gt[5][2];
@@ -172,9 +185,13 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
         for (int j = 0; j < 2; ++j) gt[i][j] = *(const u32x2*)(p.gate + (size_t)m * (size_t)p.ldg + f0 + 16 * j);
       }
     }
-    unsigned long long gbits = 0, obits = 0;
+    // gate bits of a lane and chunk: word g (= tile rows 0-2 | 3-4 ... see below) collects, in the order the epilogue visits them, the
+    // flags of its 32-bit stores (two values each): flag of the even value in the low half, of the odd value in the high half,
+    // first store highest.  20 stores -> two words of 10 + 10 bits per half.
+    uint32_t gw[2] = {0u, 0u}, ow[2] = {0u, 0u};
     if (GATE == 2) {                                           // this chunk's word was requested two chunks ago
-      gbits = gnext0;
+      gw[0] = (uint32_t)gnext0;
+      gw[1] = (uint32_t)(gnext0 >> 32);
       gnext0 = gnext1;
       if (c + 2 < nch) gnext1 = bits_p[(size_t)(c + 2) * 256];
     }
@@ -199,17 +216,21 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
     }
 
     // ---- epilogue 1 (MFMA layout: lane holds 4 consecutive hidden columns of row l15) -> 16-bit chunk image in LDS ----
+    // Vector-instruction count matters here: the launch is bound by VALU issue (4 cycles per instruction and wave, two waves per
+    // SIMD), not by the matrix pipe -- 817 vector instructions per wave and chunk against 160 MFMAs before this form.
+    const uint32_t pairc = pair0 + (uint32_t)(FC / 2) * (uint32_t)c;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      const int r = rbase + 16 * i;
-      const uint32_t m = (uint32_t)(m0 + r);                   // rows beyond M stay on chip (never stored): no clamp needed
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        const int t = 2 * i + j;                                // store pair 2t, 2t+1 of this chunk
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          v[q] = acc1[i][j][q] + b1[j][q];
-          if (p.relu) v[q] = fmaxf(v[q], 0.f);
+          v[q] = acc1[i][j][q];
+          if (EPI == 3 || EPI == 4) v[q] += b1[j][q];
+          if (EPI == 3) v[q] = fmaxf(v[q], 0.f);
+          if (EPI == 4 && p.relu) v[q] = fmaxf(v[q], 0.f);
         }
         if (GATE == 1) {
           float gv[4];
@@ -219,21 +240,35 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
         }
         if (GATE == 2) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = ((gbits >> (4 * (2 * i + j) + q)) & 1ull) ? v[q] * p.gate_scale : 0.f;
+          for (int q = 0; q < 4; ++q) {
+            const int n = (2 * t + (q >> 1)) % 10;              // position among the word's 10 stores
+            int m;                                               // 0 or -1 (as asm: the compiler turns the builtin back into and + compare + select)
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(gw[t / 5]), "n"((9 - n) + 16 * (q & 1)));
+            v[q] = __uint_as_float(__float_as_uint(v[q] * p.gate_scale) & (uint32_t)m);
+          }
         }
-        eg_dropout_run<4>(v, p.dh, seed_lo, seed_hi, m * (uint32_t)p.F + (uint32_t)(f0 + 16 * j));
-        const int hcol = 32 * wn + 16 * j + 4 * g4;            // column within the chunk
+        if (p.dh.thresh) {                                      // = eg_dropout_run<4> at element (m0 + l15 + 16 i) * F + f0 + 16 j
+          const uint32_t e = pairc + (uint32_t)(8 * j) + (uint32_t)i * pairF;
+          const uint32_t h0 = eg_hash(seed_lo, seed_hi, p.dh.site, e), h1 = eg_hash(seed_lo, seed_hi, p.dh.site, e + 1u);
+          v[0] = (h0 & 0xFFFFu) >= p.dh.thresh ? v[0] * p.dh.scale : 0.0f;
+          v[1] = (h0 >> 16) >= p.dh.thresh ? v[1] * p.dh.scale : 0.0f;
+          v[2] = (h1 & 0xFFFFu) >= p.dh.thresh ? v[2] * p.dh.scale : 0.0f;
+          v[3] = (h1 >> 16) >= p.dh.thresh ? v[3] * p.dh.scale : 0.0f;
+        }
         const u32x2 pk = f_pack4<T>(v);
-        *(u32x2*)(hc + r * 256 + (((hcol >> 3) ^ sw7) << 4) + ((hcol & 4) << 1)) = pk;
-        if (BOUT) {                                            // "stored value > 0", taken from the stored 16-bit patterns
-          const uint32_t lo = pk[0], hi = pk[1];
-          const uint32_t b4 = ((lo & 0x7fffu) && !(lo & 0x8000u) ? 1u : 0u) | ((lo & 0x7fff0000u) && !(lo & 0x80000000u) ? 2u : 0u) |
-                              ((hi & 0x7fffu) && !(hi & 0x8000u) ? 4u : 0u) | ((hi & 0x7fff0000u) && !(hi & 0x80000000u) ? 8u : 0u);
-          obits |= (unsigned long long)b4 << (4 * (2 * i + j));
+        *(u32x2*)(hc + ha[j] + 4096 * i) = pk;
+        if (BOUT) {                                            // "stored value > 0", taken from the stored 16-bit patterns:
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {                        // min(max(as int16, 0), 1) per half = 1 exactly for +x, x != 0
+            uint32_t z, f;                                       // (as asm: three instructions per store; the elementwise builtins
+            asm("v_pk_max_i16 %0, %1, 0" : "=v"(z) : "v"(pk[h]));                      // came back as compare / select / permute chains)
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(z), "v"(0x00010001u));
+            ow[t / 5] = (ow[t / 5] << 1) | f;
+          }
         }
       }
     }
-    if (BOUT) p.bits_out[((size_t)blockIdx.x * nch + c) * 256 + wn * 64 + lane] = obits;
+    if (BOUT) p.bits_out[((size_t)blockIdx.x * nch + c) * 256 + wn * 64 + lane] = (unsigned long long)ow[0] | ((unsigned long long)ow[1] << 32);
     __syncthreads();        // chunk c is complete in LDS; nobody reads buffer (c+1)&1 (chunk c-1) any more
 
     // ---- the stored result: whole 256-B row segments of the chunk, 16 B per thread ----
@@ -335,17 +370,24 @@ static int ffn_launch(const eg_ffn_desc* d, hipStream_t s) {
   p.dc2 = make_drop(d->drop_c2_p, d->drop_c2_site);
   p.gate_scale = d->gate_scale == 0.f ? 1.0f : d->gate_scale;
   const dim3 grid((d->M + FR - 1) / FR);
-#define FFN_LAUNCH(G_, B_)                                                                                             \
+#define FFN_LAUNCH(G_, B_, E_)                                                                                         \
   do {                                                                                                                 \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      (void)hipFuncSetAttribute((const void*)ffn_chain_kernel<T, G_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS); \
+      (void)hipFuncSetAttribute((const void*)ffn_chain_kernel<T, G_, B_, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS); \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((ffn_chain_kernel<T, G_, B_>), grid, dim3(256), F_LDS, s, p);                                   \
+    hipLaunchKernelGGL((ffn_chain_kernel<T, G_, B_, E_>), grid, dim3(256), F_LDS, s, p);                               \
   } while (0)
-  if (d->gate_bits_in) FFN_LAUNCH(2, 0); else if (d->gate) FFN_LAUNCH(1, 0);
-  else if (d->gate_bits_out) FFN_LAUNCH(0, 1); else FFN_LAUNCH(0, 0);
+  const int gsel = d->gate_bits_in ? 2 : d->gate ? 1 : 0;
+  const bool bout = d->gate_bits_out != nullptr;
+  if (gsel == 0 && d->bias1 && p.relu) { if (bout) FFN_LAUNCH(0, 1, 3); else FFN_LAUNCH(0, 0, 3); }          // the forward pass
+  else if (gsel == 2 && !d->bias1 && !p.relu) FFN_LAUNCH(2, 0, 0);                                           // the backward pass
+  else if (gsel == 1 && !d->bias1 && !p.relu) FFN_LAUNCH(1, 0, 0);
+  else if (gsel == 2) FFN_LAUNCH(2, 0, 4);                                                                    // anything else
+  else if (gsel == 1) FFN_LAUNCH(1, 0, 4);
+  else if (bout) FFN_LAUNCH(0, 1, 4);
+  else FFN_LAUNCH(0, 0, 4);
 #undef FFN_LAUNCH
   EG_LAUNCH_CHECK("ffn_chain");
   return 0;
