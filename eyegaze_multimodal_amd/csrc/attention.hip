@@ -98,9 +98,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   uint32_t seed_lo = 0, seed_hi = 0;
   if (dc.thresh) { seed_lo = st->seed_lo; seed_hi = st->seed_hi; }
   __syncthreads();
-  for (int qt = role; qt < nkt; qt += 2) {
+  // A LAST key tile with a single valid key (S = 16 n + 1: a class token in front of 16 n positions) evaluates ONE accumulator
+  // register per lane instead of four: the scale / max / exp / normalise / dropout chain is the kernel's bound (vector issue, not
+  // the matrix pipe), and the three masked registers are zero probabilities whatever is computed for them.  Same values, bit for bit.
+  const int ktail = ((S & 15) == 1) ? nkt - 1 : -1;
+  // every query tile's fragment is requested before the loop (the load sat in front of each tile's first MFMA)
+  FR<T> qfs[(NKT + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < (NKT + 1) / 2; ++i) {
+    const int q = (role + 2 * i) * 16 + l15;
+    qfs[i] = ld_frag_global<T>(qbase + (long long)q * ld + g * 8, q < S && role + 2 * i < nkt);
+  }
+#pragma unroll
+  for (int qi = 0; qi < (NKT + 1) / 2; ++qi) {
+    const int qt = role + 2 * qi;
+    if (qt >= nkt) break;
     const int q = qt * 16 + l15;
-    const FR<T> qf = ld_frag_global<T>(qbase + (long long)q * ld + g * 8, q < S);
+    const FR<T> qf = qfs[qi];
     f32x4 s[NKT];
     float mx = -INFINITY;
 #pragma unroll
@@ -108,12 +122,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
       s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (kt < nkt) {   // wave-uniform: key tiles beyond the sequence cost nothing (S = 65 uses 5 of the 6 tiles)
         s[kt] = H16<T>::mfma(kf[kt], qf, s[kt]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * g + r;
-          const float v = key < S ? s[kt][r] * kScale : -INFINITY;
-          s[kt][r] = v;
+        if (kt == ktail) {
+          const float v = g == 0 ? s[kt][0] * kScale : -INFINITY;
+          s[kt][0] = v;
           mx = fmaxf(mx, v);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * g + r;
+            const float v = key < S ? s[kt][r] * kScale : -INFINITY;
+            s[kt][r] = v;
+            mx = fmaxf(mx, v);
+          }
         }
       }
     }
@@ -123,11 +143,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if (kt < nkt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __expf(s[kt][r] - mx);
-          s[kt][r] = p;
+        if (kt == ktail) {
+          const float p = __expf(s[kt][0] - mx);
+          s[kt] = (f32x4){p, 0.f, 0.f, 0.f};
           sum += p;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __expf(s[kt][r] - mx);
+            s[kt][r] = p;
+            sum += p;
+          }
         }
       }
     }
@@ -139,12 +165,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if (kt < nkt) {
-        float pv[4];
+        if (kt == ktail) {
+          s[kt][0] = eg_dropout(s[kt][0] * inv, dc, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g));
+        } else {
+          float pv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pv[r] = s[kt][r] * inv;
-        eg_dropout_run<4>(pv, dc, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g));
+          for (int r = 0; r < 4; ++r) pv[r] = s[kt][r] * inv;
+          eg_dropout_run<4>(pv, dc, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[kt][r] = pv[r];
+          for (int r = 0; r < 4; ++r) s[kt][r] = pv[r];
+        }
       }
     }
     f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -370,7 +400,112 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
 // the two waves of a head exchange halves through LDS in a fixed order (bit-reproducible).  Registers: 8 NKT + 16 accumulators
 // instead of the 16 NKT of a query-major sweep, LDS 23 KB per head: three workgroups per CU, as the two-pass kernel.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int SP>
+// NKTX > 0: the tile count is a compile-time constant and, with TAIL, the last key tile holds ONE valid key (S = 16 n + 1: the
+// S = 65 windows of the benchmark); <SP, 0, false> is the general form.
+template <int N> struct eg_int { static constexpr int value = N; };
+// One key tile of the single-sweep backward (attn_bwd1_kernel): all of the wave's query pairs against key tile kt.
+template <typename T, int SP, int NKTX, bool tail>
+__device__ __forceinline__ void bwd1_key_tile(const int kt, const int S, const int nkt, const bool valid, const int lane, const char* kimg,
+                                              const char* qimg, const char* doimg, const float* lsel, const float* dl, char* pimg,
+                                              char* simg, const T* vbase, const long long ld, FR<T>& vnext, f32x4 (&accq)[SP / 16][2],
+                                              const DropCfg& dc, const uint32_t seed_lo, const uint32_t seed_hi, const uint32_t headidx,
+                                              const uint32_t Sp2, T* dqkv, const int bk, const int h, const int D) {
+  constexpr int NKT = SP / 16;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int qq = l15 >> 2, pp = l15 & 3;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  const int key = kt * 16 + l15;
+  const FR<T> kfr = ld_frag_lds_row<T>(kimg, key, g);       // the staged image (zero rows beyond S) instead of a second global read
+  const FR<T> vfr = vnext;                                   // requested one key tile ahead
+  {
+    const int key2 = key + 32;
+    vnext = ld_frag_global<T>(vbase + (long long)key2 * ld + g * 8, key2 < S && kt + 2 < nkt);
+  }
+  FR<T> ktr[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) ktr[dt] = ld_frag_lds_tr<T>(kimg, 32 * (kt >> 1), dt, lane);
+  f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
+#pragma unroll
+  for (int qp = 0; qp < NKT / 2; ++qp) {
+    if (2 * qp < nkt) {
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int qt = 2 * qp + h2;
+        const int off = (16 * h2 + l15) * 32 + g * 8;      // the block in the wave's images: query slot 16 h2 + l15, keys 4g .. 4g+3
+        if (NKTX ? qt >= NKTX : qt >= nkt) {                // a query tile beyond the sequence: zero slots, no work
+          *(u32x2*)(pimg + off) = (u32x2){0u, 0u};
+          *(u32x2*)(simg + off) = (u32x2){0u, 0u};
+          continue;
+        }
+        const int q = qt * 16 + l15;
+        const FR<T> qf = ld_frag_lds_row<T>(qimg, q, g);
+        const FR<T> dof = ld_frag_lds_row<T>(doimg, q, g);
+        const float lq = lsel[q], dq = dl[q];
+        const f32x4 sT = H16<T>::mfma(kfr, qf, zero4);
+        const f32x4 dpT = H16<T>::mfma(vfr, dof, zero4);
+        float pd[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 dsv = zero4;
+        if (tail) {
+          const float m0 = eg_dropout(1.f, dc, seed_lo, seed_hi, (headidx + (uint32_t)q) * Sp2 + (uint32_t)(kt * 16 + 4 * g));
+          const float p = (g == 0 && q < S) ? __expf(sT[0] * kScale - lq) : 0.f;
+          pd[0] = p * m0;
+          dsv[0] = p * (dpT[0] * m0 - dq);
+        } else {
+          float m[4] = {1.f, 1.f, 1.f, 1.f};
+          eg_dropout_run<4>(m, dc, seed_lo, seed_hi, (headidx + (uint32_t)q) * Sp2 + (uint32_t)(kt * 16 + 4 * g));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kk = kt * 16 + 4 * g + r;
+            const float p = (kk < S && q < S) ? __expf(sT[r] * kScale - lq) : 0.f;
+            pd[r] = p * m[r];
+            dsv[r] = p * (dpT[r] * m[r] - dq);
+          }
+        }
+        // dQ of this query tile: dS is the B operand as it stands (query lanes, key k-slots); the other key tile of the pair is zero
+        const FR<T> dsf = (kt & 1) ? pack_frag<T>(zero4, dsv) : pack_frag<T>(dsv, zero4);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) accq[qt][dt] = H16<T>::mfma(ktr[dt], dsf, accq[qt][dt]);
+        // the block into the wave's images (8 B of a 32-B row)
+        u32x2 pw, sw;
+        pw[0] = H16<T>::pack2(pd[0], pd[1]);   pw[1] = H16<T>::pack2(pd[2], pd[3]);
+        sw[0] = H16<T>::pack2(dsv[0], dsv[1]); sw[1] = H16<T>::pack2(dsv[2], dsv[3]);
+        *(u32x2*)(pimg + off) = pw;
+        *(u32x2*)(simg + off) = sw;
+      }
+      // dV, dK of this key tile: the transposed blocks (key lanes, the query pair in the k-slots) against dO^T / Q^T
+      s16x4 pa[2], sa[2];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int off = (16 * h2 + 4 * g + qq) * 32 + pp * 8;
+        pa[h2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pimg + off));
+        sa[h2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(simg + off));
+      }
+      const s16x8 pt = {pa[0][0], pa[0][1], pa[0][2], pa[0][3], pa[1][0], pa[1][1], pa[1][2], pa[1][3]};
+      const s16x8 stt = {sa[0][0], sa[0][1], sa[0][2], sa[0][3], sa[1][0], sa[1][1], sa[1][2], sa[1][3]};
+      const FR<T> pdf = __builtin_bit_cast(FR<T>, pt), dsT = __builtin_bit_cast(FR<T>, stt);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const FR<T> dotr = ld_frag_lds_tr<T>(doimg, 32 * qp, dt, lane);
+        dv[dt] = H16<T>::mfma(dotr, pdf, dv[dt]);
+        const FR<T> qtr = ld_frag_lds_tr<T>(qimg, 32 * qp, dt, lane);
+        dk[dt] = H16<T>::mfma(qtr, dsT, dk[dt]);
+      }
+    }
+  }
+  if (key < S && valid) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      float a[4] = {dk[dt][0] * kScale, dk[dt][1] * kScale, dk[dt][2] * kScale, dk[dt][3] * kScale};
+      float c[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
+      T* row = dqkv + ((long long)bk * S + key) * ld + h * 32 + 16 * dt + 4 * g;
+      store4(row + D, a);
+      store4(row + 2 * D, c);
+    }
+  }
+}
+
+template <typename T, int SP, int NKTX, bool TAIL>
 __global__ __launch_bounds__(256, SP <= 96 ? 3 : 2) void attn_bwd1_kernel(const T* __restrict__ qkv, const T* __restrict__ ctx,
                                                         const T* __restrict__ dctx, const float* __restrict__ lse,
                                                         T* __restrict__ dqkv, int NB, int S, int H, int kv_shift,
@@ -421,7 +556,8 @@ __global__ __launch_bounds__(256, SP <= 96 ? 3 : 2) void attn_bwd1_kernel(const 
     lsel[q] = l;
     dl[q] = dsum;
   }
-  const int nkt = (S + 15) >> 4;
+  const int nkt = (S + 15) >> 4;        // (run-time also when NKTX names it: the pair loop below keeps one basic block per pair --
+                                        //  with a constant count the scheduler hoisted every pair's operand reads and spilled 31 registers)
   uint32_t seed_lo = 0, seed_hi = 0;
   if (dc.thresh) { seed_lo = st->seed_lo; seed_hi = st->seed_hi; }
   const uint32_t headidx = (uint32_t)((b * H + h) * S);
@@ -436,80 +572,16 @@ __global__ __launch_bounds__(256, SP <= 96 ? 3 : 2) void attn_bwd1_kernel(const 
   const int qq = l15 >> 2, pp = l15 & 3;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  for (int kt = role; kt < nkt; kt += 2) {
-    const int key = kt * 16 + l15;
-    const FR<T> kfr = ld_frag_global<T>(kbase + (long long)key * ld + g * 8, key < S);
-    const FR<T> vfr = ld_frag_global<T>(vbase + (long long)key * ld + g * 8, key < S);
-    FR<T> ktr[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) ktr[dt] = ld_frag_lds_tr<T>(kimg, 32 * (kt >> 1), dt, lane);
-    f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
-#pragma unroll
-    for (int qp = 0; qp < NKT / 2; ++qp) {
-      if (2 * qp < nkt) {
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          const int qt = 2 * qp + h2;
-          const int q = qt * 16 + l15;
-          const FR<T> qf = ld_frag_lds_row<T>(qimg, q, g);
-          const FR<T> dof = ld_frag_lds_row<T>(doimg, q, g);
-          const float lq = lsel[q], dq = dl[q];
-          const f32x4 sT = H16<T>::mfma(kfr, qf, zero4);
-          const f32x4 dpT = H16<T>::mfma(vfr, dof, zero4);
-          float m[4] = {1.f, 1.f, 1.f, 1.f};
-          eg_dropout_run<4>(m, dc, seed_lo, seed_hi, (headidx + (uint32_t)q) * Sp2 + (uint32_t)(kt * 16 + 4 * g));
-          float pd[4];
-          f32x4 dsv;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int kk = kt * 16 + 4 * g + r;
-            const float p = (kk < S && q < S) ? __expf(sT[r] * kScale - lq) : 0.f;
-            pd[r] = p * m[r];
-            dsv[r] = p * (dpT[r] * m[r] - dq);
-          }
-          // dQ of this query tile: dS is the B operand as it stands (query lanes, key k-slots); the other key tile of the pair is zero
-          const FR<T> dsf = (kt & 1) ? pack_frag<T>(zero4, dsv) : pack_frag<T>(dsv, zero4);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) accq[qt][dt] = H16<T>::mfma(ktr[dt], dsf, accq[qt][dt]);
-          // the block into the wave's images: query slot 16 h2 + l15, keys 4g .. 4g+3 (8 B of a 32-B row)
-          const int off = (16 * h2 + l15) * 32 + g * 8;
-          u32x2 pw, sw;
-          pw[0] = H16<T>::pack2(pd[0], pd[1]);   pw[1] = H16<T>::pack2(pd[2], pd[3]);
-          sw[0] = H16<T>::pack2(dsv[0], dsv[1]); sw[1] = H16<T>::pack2(dsv[2], dsv[3]);
-          *(u32x2*)(pimg + off) = pw;
-          *(u32x2*)(simg + off) = sw;
-        }
-        // dV, dK of this key tile: the transposed blocks (key lanes, the query pair in the k-slots) against dO^T / Q^T
-        s16x4 pa[2], sa[2];
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          const int off = (16 * h2 + 4 * g + qq) * 32 + pp * 8;
-          pa[h2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pimg + off));
-          sa[h2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(simg + off));
-        }
-        const s16x8 pt = {pa[0][0], pa[0][1], pa[0][2], pa[0][3], pa[1][0], pa[1][1], pa[1][2], pa[1][3]};
-        const s16x8 stt = {sa[0][0], sa[0][1], sa[0][2], sa[0][3], sa[1][0], sa[1][1], sa[1][2], sa[1][3]};
-        const FR<T> pdf = __builtin_bit_cast(FR<T>, pt), dsT = __builtin_bit_cast(FR<T>, stt);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const FR<T> dotr = ld_frag_lds_tr<T>(doimg, 32 * qp, dt, lane);
-          dv[dt] = H16<T>::mfma(dotr, pdf, dv[dt]);
-          const FR<T> qtr = ld_frag_lds_tr<T>(qimg, 32 * qp, dt, lane);
-          dk[dt] = H16<T>::mfma(qtr, dsT, dk[dt]);
-        }
-      }
-    }
-    if (key < S && valid) {
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        float a[4] = {dk[dt][0] * kScale, dk[dt][1] * kScale, dk[dt][2] * kScale, dk[dt][3] * kScale};
-        float c[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
-        T* row = dqkv + ((long long)bk * S + key) * ld + h * 32 + 16 * dt + 4 * g;
-        store4(row + D, a);
-        store4(row + 2 * D, c);
-      }
-    }
-  }
+  // A last key tile with a single valid key (TAIL) evaluates one accumulator register per lane instead of four, and the second
+  // query tile of a pair is skipped when it lies beyond the sequence (odd tile counts): at S = 65 the wave with key tiles 0, 2, 4
+  // did 18 full blocks against the other's 12; now 10 + 5 quarter blocks against 10.  The tail tile is its own copy of the body
+  // (compile-time flag), so neither copy carries a branch inside its unrolled blocks.
+  FR<T> vnext = ld_frag_global<T>(vbase + (long long)(role * 16 + l15) * ld + g * 8, role * 16 + l15 < S && role < nkt);
+  const int nfull = TAIL ? NKTX - 1 : nkt;
+#define EG_BWD1_ARGS S, nkt, valid, lane, kimg, qimg, doimg, lsel, dl, pimg, simg, vbase, ld, vnext, accq, dc, seed_lo, seed_hi, headidx, Sp2, dqkv, bk, h, D
+  for (int kt = role; kt < nfull; kt += 2) bwd1_key_tile<T, SP, NKTX, false>(kt, EG_BWD1_ARGS);
+  if (TAIL && role == ((NKTX - 1) & 1)) bwd1_key_tile<T, SP, NKTX, true>(NKTX - 1, EG_BWD1_ARGS);
+#undef EG_BWD1_ARGS
 
   // ---- dQ: role 0 finishes query tiles [0, NKT/2), role 1 the rest; each hands the other its partial of the other's tiles ----
   __syncthreads();                                            // the images are dead: they carry the partials
@@ -518,7 +590,14 @@ __global__ __launch_bounds__(256, SP <= 96 ? 3 : 2) void attn_bwd1_kernel(const 
   for (int i = 0; i < NKT / 2; ++i) {
     const int qt = (1 - role) * (NKT / 2) + i;                // a tile the OTHER wave finishes
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) xbuf[((role * (NKT / 2) + i) * 2 + dt) * 64 + lane] = role ? accq[i][dt] : accq[NKT / 2 + i][dt];
+    for (int dt = 0; dt < 2; ++dt) {
+      // Both candidates are pinned in registers before the choice: left to itself the compiler turns "role ? accq[i] : accq[j]" (as a
+      // select or as a branch) into ONE load from a role-dependent address, which puts all of accq in scratch memory for the whole
+      // kernel (784 us against 421 us per step when that happened to the S = 65 instantiation).
+      f32x4 lo = accq[i][dt], hi = accq[NKT / 2 + i][dt];
+      asm volatile("" : "+v"(lo), "+v"(hi));
+      xbuf[((role * (NKT / 2) + i) * 2 + dt) * 64 + lane] = role ? lo : hi;
+    }
     (void)qt;
   }
   __syncthreads();
@@ -529,7 +608,9 @@ __global__ __launch_bounds__(256, SP <= 96 ? 3 : 2) void attn_bwd1_kernel(const 
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
       const f32x4 other = xbuf[(((1 - role) * (NKT / 2) + i) * 2 + dt) * 64 + lane];
-      const f32x4 mine = role ? accq[NKT / 2 + i][dt] : accq[i][dt];
+      f32x4 lo = accq[i][dt], hi = accq[NKT / 2 + i][dt];
+      asm volatile("" : "+v"(lo), "+v"(hi));
+      const f32x4 mine = role ? hi : lo;
       const f32x4 tot = role ? other + mine : mine + other;    // fixed order: role 0's partial + role 1's partial
       if (q < S && valid) {
         float v[4] = {tot[0] * kScale, tot[1] * kScale, tot[2] * kScale, tot[3] * kScale};
@@ -682,11 +763,16 @@ int launch_bwd(const void* qkv, const void* ctx, const void* dctx, const float* 
     constexpr int lds1 = 2 * (3 * SP * 64 + 2 * SP * 4 + 2 * 2 * 32 * 32);
     static bool attr1 = false;
     if (!attr1) {
-      (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<T, (SP <= 128 ? SP : 96)>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+      (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<T, (SP <= 128 ? SP : 96), 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+      (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<T, 96, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
       attr1 = true;
     }
-    hipLaunchKernelGGL((attn_bwd1_kernel<T, (SP <= 128 ? SP : 96)>), dim3(nblk), dim3(256), lds1, s, (const T*)qkv, (const T*)ctx,
-                       (const T*)dctx, lse, (T*)dqkv, NB, S, H, kv_shift, dc, st);
+    if (SP == 96 && S == 65)           // class token + 64 positions: exact tile count, single-key tail tile
+      hipLaunchKernelGGL((attn_bwd1_kernel<T, 96, 5, true>), dim3(nblk), dim3(256), lds1, s, (const T*)qkv, (const T*)ctx,
+                         (const T*)dctx, lse, (T*)dqkv, NB, S, H, kv_shift, dc, st);
+    else
+      hipLaunchKernelGGL((attn_bwd1_kernel<T, (SP <= 128 ? SP : 96), 0, false>), dim3(nblk), dim3(256), lds1, s, (const T*)qkv, (const T*)ctx,
+                         (const T*)dctx, lse, (T*)dqkv, NB, S, H, kv_shift, dc, st);
     return 0;
   }
   constexpr int lds = 2 * (3 * SP * 64 + 2 * SP * 4);

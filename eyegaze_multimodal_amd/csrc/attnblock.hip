@@ -88,7 +88,10 @@ __device__ __forceinline__ typename H16<T>::frag ab_pack_frag(const f32x4& a, co
   return __builtin_bit_cast(typename H16<T>::frag, v);
 }
 
-template <typename T>
+// NKTX > 0: the tile count is a compile-time constant (no wave-uniform branches inside the unrolled tile loops: the scheduler
+// sees one straight-line body per query tile); TAIL: the last key tile holds ONE valid key (S = 16 n + 1) and evaluates one
+// accumulator register per lane.  <0, false> is the general form.
+template <typename T, int NKTX, bool TAIL>
 __global__ __launch_bounds__(256, 2) void attn_block_fwd_kernel(ABArgs<T> p) {
   typedef typename H16<T>::frag frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_fwd_kernel(ABArgs<T> p) {
   const int b = blockIdx.x;                      // the window this workgroup owns
   const int S = p.S;
   const size_t row0 = (size_t)b * (size_t)S;     // its first token row
-  const int nkt = (S + 15) >> 4;                 // key / query tiles in use (<= 5)
+  const int nkt = NKTX ? NKTX : (S + 15) >> 4;   // key / query tiles in use (<= 5)
 
   // ---- x tile: instruction q moves rows 2q, 2q+1 (lane -> row half lane/32, LDS chunk position lane%32 holding global chunk
   //      pos ^ (row & 7)); rows beyond S repeat row S-1 (finite values that never reach a stored result) ----
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_fwd_kernel(ABArgs<T> p) {
     // ================= P2: attention of head 2c + hh, query tiles role, role + 2, .. =================
     {
       const int h = 2 * c + hh;
+      constexpr int ktail = TAIL ? NKTX - 1 : -1;
       frag kf[5];
 #pragma unroll
       for (int kt = 0; kt < 5; ++kt) kf[kt] = ab_frag_row<T>(kimg, kt * 16 + l15, g4);
@@ -235,12 +239,18 @@ __global__ __launch_bounds__(256, 2) void attn_block_fwd_kernel(ABArgs<T> p) {
           s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (kt < 5 && kt < nkt) {
             s[kt] = H16<T>::mfma(kf[kt < 5 ? kt : 0], qf, s[kt]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int key = kt * 16 + 4 * g4 + r;
-              const float v = key < S ? s[kt][r] * kAScale : -INFINITY;
-              s[kt][r] = v;
+            if (kt == ktail) {                               // single valid key: one accumulator register (csrc/attention.hip)
+              const float v = g4 == 0 ? s[kt][0] * kAScale : -INFINITY;
+              s[kt][0] = v;
               mx = fmaxf(mx, v);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * g4 + r;
+                const float v = key < S ? s[kt][r] * kAScale : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+              }
             }
           }
         }
@@ -250,11 +260,17 @@ __global__ __launch_bounds__(256, 2) void attn_block_fwd_kernel(ABArgs<T> p) {
 #pragma unroll
         for (int kt = 0; kt < 5; ++kt) {
           if (kt < nkt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float pe = __expf(s[kt][r] - mx);
-              s[kt][r] = pe;
+            if (kt == ktail) {
+              const float pe = __expf(s[kt][0] - mx);
+              s[kt] = (f32x4){pe, 0.f, 0.f, 0.f};
               sum += pe;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float pe = __expf(s[kt][r] - mx);
+                s[kt][r] = pe;
+                sum += pe;
+              }
             }
           }
         }
@@ -266,12 +282,16 @@ __global__ __launch_bounds__(256, 2) void attn_block_fwd_kernel(ABArgs<T> p) {
 #pragma unroll
         for (int kt = 0; kt < 5; ++kt) {
           if (kt < nkt) {
-            float pv[4];
+            if (kt == ktail) {
+              s[kt][0] = eg_dropout(s[kt][0] * inv, p.da, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g4));
+            } else {
+              float pv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pv[r] = s[kt][r] * inv;
-            eg_dropout_run<4>(pv, p.da, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g4));
+              for (int r = 0; r < 4; ++r) pv[r] = s[kt][r] * inv;
+              eg_dropout_run<4>(pv, p.da, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g4));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[kt][r] = pv[r];
+              for (int r = 0; r < 4; ++r) s[kt][r] = pv[r];
+            }
           }
         }
         f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -375,10 +395,12 @@ static int ab_launch(const eg_attn_block_desc* d, hipStream_t s) {
   p.d1 = make_drop(d->out_drop_p, d->out_drop_site);
   static bool attr = false;                      // (one flag per instantiation)
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_block_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_block_fwd_kernel<T, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_block_fwd_kernel<T, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS);
     attr = true;
   }
-  hipLaunchKernelGGL((attn_block_fwd_kernel<T>), dim3(d->NB), dim3(256), A_LDS, s, p);
+  if (d->S == 65) hipLaunchKernelGGL((attn_block_fwd_kernel<T, 5, true>), dim3(d->NB), dim3(256), A_LDS, s, p);   // class token + 64 positions
+  else hipLaunchKernelGGL((attn_block_fwd_kernel<T, 0, false>), dim3(d->NB), dim3(256), A_LDS, s, p);
   EG_LAUNCH_CHECK("attn_block_fwd");
   return 0;
 }
