@@ -471,11 +471,25 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_grouped_kernel(const eg_tn_pro
 // 256 columns, 16-B chunks XOR-swizzled by tn_swz), same transposed fragment reads, same k-ordered accumulation per output
 // element as tn_body: the partial slabs are bit-identical to the 128 x 128 tile's for equal row splits.
 // ------------------------------------------------------------------------------------------------
+// 512 zero bytes: the LDS-DMA source of the rows beyond a split's end (a DMA cannot write a constant)
+__device__ __attribute__((aligned(512))) char eg_zero_row[512];
+
+__device__ __forceinline__ void tn_dma16(const char* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// 256 x 256 weight-gradient tile over one row split.  The loop is fed by LDS-DMA through a FOUR-stage ring of 32-row stages
+// (2 x 16 KB each, 128 KB): three stages = 96 KB per CU are always in flight behind the one being multiplied.  (Before: 64-row
+// stages staged through registers, ONE stage in flight -- requested after a barrier, needed one multiply phase later -- so every
+// iteration cost one HBM latency: 5 600 cycles per 64 rows against 1 024 cycles of MFMA, 3.9 TB/s by the PMC counters.)
+// One raw barrier per stage; counted s_waitcnt vmcnt(N) (each wave issues exactly four DMAs per stage).
 template <typename T>
 __device__ __forceinline__ void tn_body256(const GemmTN<T>& p, const int split, const int t, char* smem) {
-  constexpr int ROWB = 512, RS = 64, TILEB = RS * ROWB;       // 32 KiB per operand and stage
+  constexpr int ROWB = 512, RS = 32, TILEB = RS * ROWB, STAGEB = 2 * TILEB, NST = 4;    // 16 KiB per operand and stage
   typedef typename H16<T>::frag frag;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wk = wave >> 1, wn = wave & 1;
   const int n0 = (t / p.tiles_k) * 256, k0 = (t % p.tiles_k) * 256;
   const int mbeg = split * p.rows_per_split;
@@ -487,82 +501,90 @@ __device__ __forceinline__ void tn_body256(const GemmTN<T>& p, const int split, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // staging map: chunk id c = tid + 512*i -> row = c / 32, chunk-in-row = c % 32
-  u32x4 ry[4], rx[4];
-  auto load_tile = [&](int mt) {
+  // DMA map: an instruction moves rows 2q, 2q+1 of a stage (lane -> row half lane / 32, LDS chunk position lane % 32 holding the
+  // row's chunk pos ^ swz(row)); wave w issues q = w and w + 8 of dY and of X
+  const int dhalf = lane >> 5, dpos = lane & 31;
+  const char* const zsrc = eg_zero_row + dpos * 16;
+  auto issue = [&](int it) {
+    char* st = smem + (it & (NST - 1)) * STAGEB;
+    const int mt = mbeg + it * RS;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 512 * i;
-      const int row = c >> 5, ch = c & 31;
+    for (int i = 0; i < 2; ++i) {
+      const int q = wave + 8 * i;
+      const int row = 2 * q + dhalf;
       const int m = mt + row;
-      u32x4 z = {0u, 0u, 0u, 0u};
-      ry[i] = z;
-      rx[i] = z;
-      if (m < mend) {
-        ry[i] = *(const u32x4*)(p.dY + row_off(p.y, m) + n0 + ch * 8);
-        rx[i] = *(const u32x4*)(p.X + row_off(p.x, m) + k0 + ch * 8);
-      }
-    }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 512 * i;
-      const int row = c >> 5, ch = c & 31;
-      const int off = row * ROWB + ((ch ^ tn_swz(row)) << 4);
-      *(u32x4*)(smem + off) = ry[i];
-      *(u32x4*)(smem + TILEB + off) = rx[i];
+      const int ch = (dpos ^ tn_swz(row)) << 4;
+      const bool ok = m < mend;
+      const int mc = ok ? m : mend - 1;
+      const char* sy = (const char*)(p.dY + row_off(p.y, mc) + n0) + ch;
+      const char* sx = (const char*)(p.X + row_off(p.x, mc) + k0) + ch;
+      tn_dma16(ok ? sy : zsrc, st + q * 1024);
+      tn_dma16(ok ? sx : zsrc, st + TILEB + q * 1024);
     }
   };
   const int nt = (mend - mbeg + RS - 1) / RS;
   const bool do_bias = p.has_bias && (t % p.tiles_k) == 0;
   float bsum = 0.f;
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-  if (nt > 0) load_tile(mbeg);
-  for (int it = 0; it < nt; ++it) {
-    store_tile();
-    __syncthreads();
-    if (it + 1 < nt) load_tile(mbeg + (it + 1) * RS);
 #pragma unroll
-    for (int sub = 0; sub < RS / 32; ++sub) {
-      const char* bufY = smem + sub * 32 * ROWB;
-      const char* bufX = smem + TILEB + sub * 32 * ROWB;
+  for (int i = 0; i < NST - 1; ++i)
+    if (i < nt) issue(i);
+  for (int it = 0; it < nt; ++it) {
+    // this wave's part of stage `it` has landed once only the later stages' DMAs (four each) are outstanding
+    const int later = min(NST - 2, nt - 1 - it);
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage it visible to all; nobody reads stage it - 1 any more
+    if (it + NST - 1 < nt) issue(it + NST - 1);                        // ... so its buffer takes stage it + 3
+    asm volatile("" ::: "memory");
+    {
+      const char* bufY = smem + (it & (NST - 1)) * STAGEB;
+      const char* bufX = bufY + TILEB;
+      // The transposed fragment reads are inline asm: as builtins (or plain loads) they carry LDS memory operands, and the compiler
+      // then puts an s_waitcnt vmcnt(0) in front of them because an LDS-DMA "may alias" -- which drains the very ring this loop
+      // keeps in flight.  The counted wait above is the real dependency; the lgkmcnt wait below is tied to the fragments.
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      const int r = 8 * g + q;                                 // row of half h: r + 4 h (same swizzle: tn_swz ignores bit 2)
+      const uint32_t ly = (uint32_t)(size_t)(__attribute__((address_space(3))) const char*)bufY + r * ROWB;
+      const uint32_t lx = ly + TILEB;
+      const int fsw = tn_swz(r);
+      s16x4 yp[8][2], xp[4][2];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int cy = wn * 128 + i * 16 + 4 * pp;
+        const uint32_t a = ly + (((cy >> 3) ^ fsw) << 4) + ((cy >> 2) & 1) * 8;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(yp[i][0]) : "v"(a));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(yp[i][1]) : "v"(a));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cx = wk * 64 + i * 16 + 4 * pp;
+        const uint32_t a = lx + (((cx >> 3) ^ fsw) << 4) + ((cx >> 2) & 1) * 8;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xp[i][0]) : "v"(a));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(xp[i][1]) : "v"(a));
+      }
       frag yf[8], xf[4];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        s16x4 part[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int r = 8 * g + 4 * h + q;
-          const int cy = wn * 128 + i * 16 + 4 * pp;
-          part[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(bufY + r * ROWB + (((cy >> 3) ^ tn_swz(r)) << 4) + ((cy >> 2) & 1) * 8));
-        }
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        s16x8 ty = {part[0][0], part[0][1], part[0][2], part[0][3], part[1][0], part[1][1], part[1][2], part[1][3]};
+        s16x8 ty = {yp[i][0][0], yp[i][0][1], yp[i][0][2], yp[i][0][3], yp[i][1][0], yp[i][1][1], yp[i][1][2], yp[i][1][3]};
         yf[i] = __builtin_bit_cast(frag, ty);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        s16x4 part[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int r = 8 * g + 4 * h + q;
-          const int cx = wk * 64 + i * 16 + 4 * pp;
-          part[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(bufX + r * ROWB + (((cx >> 3) ^ tn_swz(r)) << 4) + ((cx >> 2) & 1) * 8));
-        }
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        s16x8 tx = {part[0][0], part[0][1], part[0][2], part[0][3], part[1][0], part[1][1], part[1][2], part[1][3]};
+        s16x8 tx = {xp[i][0][0], xp[i][0][1], xp[i][0][2], xp[i][0][3], xp[i][1][0], xp[i][1][1], xp[i][1][2], xp[i][1][3]};
         xf[i] = __builtin_bit_cast(frag, tx);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(yf[0]), "+v"(yf[1]), "+v"(yf[2]), "+v"(yf[3]), "+v"(yf[4]), "+v"(yf[5]), "+v"(yf[6]), "+v"(yf[7]),
+                     "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]));
 #pragma unroll
       for (int ki = 0; ki < 4; ++ki)
 #pragma unroll
         for (int ni = 0; ni < 8; ++ni) acc[ki][ni] = H16<T>::mfma(xf[ki], yf[ni], acc[ki][ni]);
-      if (do_bias) {       // column sums of the dY tile: thread -> column tid & 255, rows 16 * (tid >> 8) .. +15 of the sub-stage
+      if (do_bias) {       // column sums of the dY stage: thread -> column tid & 255, rows 16 * (tid >> 8) .. +15
         const int col = tid & 255, half = tid >> 8;
-        float s16 = 0.f;                                  // (summed per sub-stage first, as tn_tile_colsum does: same rounding)
+        float s16 = 0.f;                                  // (summed per 16 rows first, as tn_tile_colsum does: same rounding)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int r = half * 16 + i;
@@ -571,8 +593,8 @@ __device__ __forceinline__ void tn_body256(const GemmTN<T>& p, const int split, 
         bsum += s16;
       }
     }
-    __syncthreads();
   }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave has left the ring (the bias sums reuse it)
   float* out = p.partial + (size_t)split * p.slab;
   const int l15 = lane & 15;
 #pragma unroll
@@ -874,7 +896,7 @@ static int launch_gemm_tn(const eg_gemm_tn_desc* d, hipStream_t s) {
     if (d->tile == 256) {
       p.tiles_k = d->K / 256;
       p.tiles_nk = p.tiles_k * (d->N / 256);
-      constexpr int lds256 = 2 * 64 * 512;
+      constexpr int lds256 = 4 * 2 * 32 * 512;          // tn_body256's four-stage ring
       static bool attr = false;
       if (!attr) {
         (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
@@ -995,7 +1017,7 @@ extern "C" int eg_gemm_tn_grouped256(const eg_tn_problem* probs, int nprob, int 
   int rps = (M + splits - 1) / splits;
   rps = (rps + 63) / 64 * 64;
   hipStream_t s = (hipStream_t)stream;
-  constexpr int lds = 2 * 64 * 512;
+  constexpr int lds = 4 * 2 * 32 * 512;                  // tn_body256's four-stage ring
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_grouped256_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
