@@ -13,7 +13,7 @@ LIB_PATH = _PKG / "libeyegaze_hip.so"
 
 EG_F32, EG_BF16, EG_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class EgError(RuntimeError):
@@ -57,14 +57,16 @@ class FfnDesc(C.Structure):
                 ("M", C.c_int32), ("F", C.c_int32), ("act1", C.c_int32), ("dtype", C.c_int32),
                 ("drop_h_p", C.c_float), ("drop_c1_p", C.c_float), ("drop_c2_p", C.c_float),
                 ("drop_h_site", C.c_uint32), ("drop_c1_site", C.c_uint32), ("drop_c2_site", C.c_uint32),
-                ("gate_scale", C.c_float)]
+                ("gate_scale", C.c_float),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_out", C.c_void_p), ("ln_stats", C.c_void_p)]
 
 
 class AttnBlockDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("wqkv_frag", C.c_void_p), ("wo_frag", C.c_void_p), ("bqkv", C.c_void_p), ("bo", C.c_void_p),
                 ("qkv", C.c_void_p), ("ctx", C.c_void_p), ("lse", C.c_void_p), ("r1", C.c_void_p), ("state", C.c_void_p),
                 ("NB", C.c_int32), ("S", C.c_int32), ("d_model", C.c_int32), ("num_heads", C.c_int32), ("dtype", C.c_int32),
-                ("attn_drop_p", C.c_float), ("out_drop_p", C.c_float), ("attn_drop_site", C.c_uint32), ("out_drop_site", C.c_uint32)]
+                ("attn_drop_p", C.c_float), ("out_drop_p", C.c_float), ("attn_drop_site", C.c_uint32), ("out_drop_site", C.c_uint32),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_out", C.c_void_p), ("ln_stats", C.c_void_p)]
 
 
 class PackEntry(C.Structure):

@@ -65,6 +65,28 @@ __device__ __forceinline__ void stage_rows(char* img, const T* src, long long ld
   }
 }
 
+// stage_rows in two halves, so that a kernel can request SEVERAL images (and whatever else its prologue reads) before the first wait:
+// every load -> wait -> LDS store pair left to itself cost one HBM latency (stamped: 9 200 cycles for the three images of the
+// single-sweep backward, 28 % of a wave's lifetime)
+template <typename T, int NCH>
+__device__ __forceinline__ void rows_request(u32x4 (&r)[NCH], const T* src, long long ld, int S, int first) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int id = first + 128 * i;
+    const int row = id >> 2, c4 = id & 3;
+    r[i] = (u32x4){0u, 0u, 0u, 0u};
+    if (row < S) r[i] = *(const u32x4*)(src + (long long)row * ld + c4 * 8);
+  }
+}
+template <int NCH>
+__device__ __forceinline__ void rows_store(char* img, const u32x4 (&r)[NCH], int SP, int first) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int id = first + 128 * i;
+    if (id < SP * 4) *(u32x4*)(img + img_chunk_off(id >> 2, id & 3)) = r[i];
+  }
+}
+
 constexpr float kScale = 0.17677669529663687f;  // 1/sqrt(32)
 
 template <typename T, int SP>
@@ -87,7 +109,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   const T* kbase = qkv + (long long)bk * S * ld + D + h * 32;
   const T* vbase = kbase + D;
   char* vimg = smem + (wave >> 1) * (SP * 64);
-  stage_rows<T>(vimg, vbase, ld, S, SP, lane + 64 * role, 128);
+  constexpr int NCH = SP / 32;
+  u32x4 rv[NCH];
+  rows_request<T, NCH>(rv, vbase, ld, S, lane + 64 * role);    // (stored below, after every other request of the prologue)
   const int nkt = (S + 15) >> 4;
   FR<T> kf[NKT];
 #pragma unroll
@@ -97,7 +121,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   }
   uint32_t seed_lo = 0, seed_hi = 0;
   if (dc.thresh) { seed_lo = st->seed_lo; seed_hi = st->seed_hi; }
-  __syncthreads();
   // A LAST key tile with a single valid key (S = 16 n + 1: a class token in front of 16 n positions) evaluates ONE accumulator
   // register per lane instead of four: the scale / max / exp / normalise / dropout chain is the kernel's bound (vector issue, not
   // the matrix pipe), and the three masked registers are zero probabilities whatever is computed for them.  Same values, bit for bit.
@@ -109,6 +132,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     const int q = (role + 2 * i) * 16 + l15;
     qfs[i] = ld_frag_global<T>(qbase + (long long)q * ld + g * 8, q < S && role + 2 * i < nkt);
   }
+  rows_store<NCH>(vimg, rv, SP, lane + 64 * role);
+  __syncthreads();
 #pragma unroll
   for (int qi = 0; qi < (NKT + 1) / 2; ++qi) {
     const int qt = role + 2 * qi;
@@ -229,24 +254,49 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
   char* doimg = base + 2 * SP * 64;
   float* lsel = (float*)(base + 3 * SP * 64);
   float* dl = lsel + SP;
-  stage_rows<T>(qimg, qbase, ld, S, SP, lane + 64 * role, 128);
-  stage_rows<T>(kimg, kbase, ld, S, SP, lane + 64 * role, 128);
-  stage_rows<T>(doimg, dobase, D, S, SP, lane + 64 * role, 128);
-  for (int q = lane + 64 * role; q < SP; q += 128) {
-    float l = 0.f, dsum = 0.f;
+  // every global read of the prologue is requested before the first wait (see rows_request)
+  constexpr int NCH = SP / 32, NQ = (SP + 127) / 128;
+  const int first = lane + 64 * role;
+  u32x4 rq[NCH], rk[NCH], rd[NCH];
+  rows_request<T, NCH>(rq, qbase, ld, S, first);
+  rows_request<T, NCH>(rk, kbase, ld, S, first);
+  rows_request<T, NCH>(rd, dobase, D, S, first);
+  u32x4 da[NQ][4], oa[NQ][4];
+  float lq0[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int q = first + 128 * j;
+    lq0[j] = 0.f;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) { da[j][c4] = (u32x4){0u, 0u, 0u, 0u}; oa[j][c4] = (u32x4){0u, 0u, 0u, 0u}; }
     if (q < S) {
-      l = lse[((long long)b * H + h) * S + q];
+      lq0[j] = lse[((long long)b * H + h) * S + q];
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        da[j][c4] = *(const u32x4*)(dobase + (long long)q * D + c4 * 8);
+        oa[j][c4] = *(const u32x4*)(obase + (long long)q * D + c4 * 8);
+      }
+    }
+  }
+  rows_store<NCH>(qimg, rq, SP, first);
+  rows_store<NCH>(kimg, rk, SP, first);
+  rows_store<NCH>(doimg, rd, SP, first);
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int q = first + 128 * j;
+    if (q < SP) {
+      float dsum = 0.f;
 #pragma unroll
       for (int c4 = 0; c4 < 4; ++c4) {
         float a[8], o[8];
-        load8(dobase + (long long)q * D + c4 * 8, a);
-        load8(obase + (long long)q * D + c4 * 8, o);
+        load8((const T*)&da[j][c4], a);
+        load8((const T*)&oa[j][c4], o);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dsum += a[e] * o[e];
       }
+      lsel[q] = lq0[j];
+      dl[q] = dsum;
     }
-    lsel[q] = l;
-    dl[q] = dsum;
   }
   const int nkt = (S + 15) >> 4;
   FR<T> kf[NKT], vf[NKT];
@@ -537,24 +587,43 @@ __global__ __launch_bounds__(256, SP <= 96 ? 3 : 2) void attn_bwd1_kernel(const 
   float* dl = lsel + SP;
   char* pimg = base + 3 * IMG + 2 * SP * 4 + role * SCR;
   char* simg = pimg + 32 * 32;
-  stage_rows<T>(qimg, qbase, ld, S, SP, lane + 64 * role, 128);
-  stage_rows<T>(kimg, kbase, ld, S, SP, lane + 64 * role, 128);
-  stage_rows<T>(doimg, dobase, D, S, SP, lane + 64 * role, 128);
-  for (int q = lane + 64 * role; q < SP; q += 128) {
-    float l = 0.f, dsum = 0.f;
-    if (q < S) {
-      l = lse[((long long)b * H + h) * S + q];
+  // every global read of the prologue is requested before the first wait: the three images (this wave's half) and the lane's
+  // dO / O rows and log-sum-exp for delta = rowsum(dO * O)
+  constexpr int NCH = SP / 32;                               // 16-B chunks per lane and image: SP * 4 / 128
+  const int first = lane + 64 * role;
+  u32x4 rq[NCH], rk[NCH], rd[NCH];
+  rows_request<T, NCH>(rq, qbase, ld, S, first);
+  rows_request<T, NCH>(rk, kbase, ld, S, first);
+  rows_request<T, NCH>(rd, dobase, D, S, first);
+  static_assert(SP <= 128, "one delta row per lane");
+  const int qd = first;                                      // (the loop `for (q = first; q < SP; q += 128)` has one trip)
+  u32x4 da[4], oa[4];
+  float lq0 = 0.f;
 #pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) {
-        float a[8], o[8];
-        load8(dobase + (long long)q * D + c4 * 8, a);
-        load8(obase + (long long)q * D + c4 * 8, o);
+  for (int c4 = 0; c4 < 4; ++c4) { da[c4] = (u32x4){0u, 0u, 0u, 0u}; oa[c4] = (u32x4){0u, 0u, 0u, 0u}; }
+  if (qd < S) {
+    lq0 = lse[((long long)b * H + h) * S + qd];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dsum += a[e] * o[e];
-      }
+    for (int c4 = 0; c4 < 4; ++c4) {
+      da[c4] = *(const u32x4*)(dobase + (long long)qd * D + c4 * 8);
+      oa[c4] = *(const u32x4*)(obase + (long long)qd * D + c4 * 8);
     }
-    lsel[q] = l;
-    dl[q] = dsum;
+  }
+  rows_store<NCH>(qimg, rq, SP, first);
+  rows_store<NCH>(kimg, rk, SP, first);
+  rows_store<NCH>(doimg, rd, SP, first);
+  if (qd < SP) {
+    float dsum = 0.f;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      float a[8], o[8];
+      load8((const T*)&da[c4], a);
+      load8((const T*)&oa[c4], o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsum += a[e] * o[e];
+    }
+    lsel[qd] = lq0;
+    dl[qd] = dsum;
   }
   const int nkt = (S + 15) >> 4;        // (run-time also when NKTX names it: the pair loop below keeps one basic block per pair --
                                         //  with a constant count the scheduler hoisted every pair's operand reads and spilled 31 registers)

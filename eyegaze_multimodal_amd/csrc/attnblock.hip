@@ -47,6 +47,7 @@ template <typename T>
 struct ABArgs {
   const T* X; const T* Wqkv; const T* Wo; const float* bqkv; const float* bo;
   T* QKV; T* CTX; float* LSE; T* R1;
+  const float* ln_gamma; const float* ln_beta; T* LN_OUT; float* ln_stats;     // LNF: y = LayerNorm(r1) in the final epilogue
   const eg_step_state* st;
   int NB, S;
   DropCfg da, d1;
@@ -90,8 +91,9 @@ __device__ __forceinline__ typename H16<T>::frag ab_pack_frag(const f32x4& a, co
 
 // NKTX > 0: the tile count is a compile-time constant (no wave-uniform branches inside the unrolled tile loops: the scheduler
 // sees one straight-line body per query tile); TAIL: the last key tile holds ONE valid key (S = 16 n + 1) and evaluates one
-// accumulator register per lane.  <0, false> is the general form.
-template <typename T, int NKTX, bool TAIL>
+// accumulator register per lane.  <0, false> is the general form.  LNF: the layer's first LayerNorm (A:293) runs in the final
+// epilogue on the rows the workgroup has just completed (eg_epilogue_layernorm256) instead of as a launch that re-reads r1.
+template <typename T, int NKTX, bool TAIL, bool LNF>
 __global__ __launch_bounds__(256, 2) void attn_block_fwd_kernel(ABArgs<T> p) {
   typedef typename H16<T>::frag frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -351,6 +353,13 @@ __global__ __launch_bounds__(256, 2) void attn_block_fwd_kernel(ABArgs<T> p) {
   float bv[16];
   load8(p.bo + n, bv);
   load8(p.bo + n + 8, bv + 8);
+  float vv[LNF ? 5 : 1][16];                       // LNF: the stored r1 values of this lane's rows, for the LayerNorm below
+  if (LNF) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) vv[i][j] = 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const int r = 16 * i + er;
@@ -381,8 +390,14 @@ __global__ __launch_bounds__(256, 2) void attn_block_fwd_kernel(ABArgs<T> p) {
       T* pc = p.R1 + m * AD + n;
       store8(pc, v);
       store8(pc + 8, v + 8);
+      if (LNF) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) vv[i][j] = round_store<T>(v[j]);
+      }
     }
   }
+  if constexpr (LNF)
+    eg_epilogue_layernorm256<T>(vv, (float*)(imgs + 4 * (16 * A_TP * 4)), wn, lane, S, row0, p.ln_gamma, p.ln_beta, p.LN_OUT, p.ln_stats);
 }
 
 template <typename T>
@@ -393,14 +408,20 @@ static int ab_launch(const eg_attn_block_desc* d, hipStream_t s) {
   p.NB = d->NB; p.S = d->S;
   p.da = make_drop(d->attn_drop_p, d->attn_drop_site);
   p.d1 = make_drop(d->out_drop_p, d->out_drop_site);
-  static bool attr = false;                      // (one flag per instantiation)
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_block_fwd_kernel<T, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS);
-    (void)hipFuncSetAttribute((const void*)attn_block_fwd_kernel<T, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS);
-    attr = true;
-  }
-  if (d->S == 65) hipLaunchKernelGGL((attn_block_fwd_kernel<T, 5, true>), dim3(d->NB), dim3(256), A_LDS, s, p);   // class token + 64 positions
-  else hipLaunchKernelGGL((attn_block_fwd_kernel<T, 0, false>), dim3(d->NB), dim3(256), A_LDS, s, p);
+  p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.LN_OUT = (T*)d->ln_out; p.ln_stats = d->ln_stats;
+  const bool lnf = d->ln_out != nullptr;
+#define AB_LAUNCH(N_, T_, L_)                                                                                                  \
+  do {                                                                                                                         \
+    static bool attr = false;                                                                                                  \
+    if (!attr) {                                                                                                               \
+      (void)hipFuncSetAttribute((const void*)attn_block_fwd_kernel<T, N_, T_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS); \
+      attr = true;                                                                                                             \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((attn_block_fwd_kernel<T, N_, T_, L_>), dim3(d->NB), dim3(256), A_LDS, s, p);                           \
+  } while (0)
+  if (d->S == 65) { if (lnf) AB_LAUNCH(5, true, true); else AB_LAUNCH(5, true, false); }     // class token + 64 positions
+  else { if (lnf) AB_LAUNCH(0, false, true); else AB_LAUNCH(0, false, false); }
+#undef AB_LAUNCH
   EG_LAUNCH_CHECK("attn_block_fwd");
   return 0;
 }
@@ -418,6 +439,8 @@ extern "C" int eg_attn_block_fwd(const eg_attn_block_desc* d, void* stream) {
            "eg_attn_block_fwd: needs a 16-bit dtype, d_model == 256, 8 heads and S <= 80 (got dtype %d, d %d, H %d, S %d)", d->dtype,
            d->d_model, d->num_heads, d->S);
   EG_CHECK(d->NB > 0 && (long long)d->NB * d->S * 768 < (1ll << 31), "eg_attn_block_fwd: NB=%d", d->NB);
+  EG_CHECK(!d->ln_out || (d->ln_gamma && d->ln_beta && (uintptr_t)d->ln_out % 16 == 0),
+           "eg_attn_block_fwd: the fused LayerNorm needs gamma, beta and a 16-B aligned output");
   EG_CHECK((long long)d->NB * AH * d->S * ((d->S + 1) & ~1) < (1ll << 32), "eg_attn_block_fwd: NB*H*S*S exceeds the 32-bit dropout index");
   const float ps[2] = {d->attn_drop_p, d->out_drop_p};
   for (float q : ps) EG_CHECK(q >= 0.f && q < 1.f, "eg_attn_block_fwd: dropout p");

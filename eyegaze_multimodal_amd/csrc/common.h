@@ -238,6 +238,65 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over d_model = 256 as the tail of a row-complete epilogue (eg_attn_block_fwd -> ln1, eg_ffn_chain forward -> ln2):
+// four waves own the 256 columns of an 80-row tile (wave wn: columns 64 wn .. +63), and after the final epilogue lane
+// (er = lane / 4, ec = lane % 4) holds, per 16-row tile i, the 16 STORED values vv[i][0..15] of row 16 i + er, columns
+// 64 wn + 16 ec ..  Two-pass statistics as layernorm_fwd256_kernel (mean, then sum of squared deviations; eps 1e-5), the row sums
+// gathered across the quad by two shuffles and across the waves through `red` (LDS, 2 x 4 x 80 floats): two workgroup barriers per
+// launch instead of a launch of its own that re-reads the rows.  The summation ORDER differs from the stand-alone kernel's, so the
+// outputs agree with it to rounding (tests/test_gpu_lnfuse.py), not bit for bit.  Rows >= nvalid are skipped (vv must be 0 there).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void eg_epilogue_layernorm256(const float (&vv)[5][16], float* red, int wn, int lane, int nvalid, size_t row0,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         T* __restrict__ out, float* __restrict__ stats) {
+  const int er = lane >> 2, ec = lane & 3;
+  const int n = 64 * wn + 16 * ec;
+  float* const rs = red;                 // [4][80] row sums per wave
+  float* const rq = red + 4 * 80;        // [4][80] sums of squared deviations
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += vv[i][j];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (ec == 0) rs[wn * 80 + 16 * i + er] = s;
+  }
+  __syncthreads();
+  float mean[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int r = 16 * i + er;
+    mean[i] = (((rs[r] + rs[80 + r]) + rs[160 + r]) + rs[240 + r]) * (1.0f / 256.f);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const float d = vv[i][j] - mean[i]; q += d * d; }
+    q += __shfl_xor(q, 1, 64);
+    q += __shfl_xor(q, 2, 64);
+    if (ec == 0) rq[wn * 80 + r] = q;
+  }
+  __syncthreads();
+  float g[16], bt[16];
+  load8(gamma + n, g); load8(gamma + n + 8, g + 8);
+  load8(beta + n, bt); load8(beta + n + 8, bt + 8);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int r = 16 * i + er;
+    if (r < nvalid) {
+      const float rstd = rsqrtf((((rq[r] + rq[80 + r]) + rq[160 + r]) + rq[240 + r]) * (1.0f / 256.f) + 1e-5f);
+      float o[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[j] = (vv[i][j] - mean[i]) * rstd * g[j] + bt[j];
+      T* po = out + (row0 + r) * 256 + n;
+      store8(po, o);
+      store8(po + 8, o + 8);
+      if (stats && wn == 0 && ec == 0) { stats[2 * (row0 + r)] = mean[i]; stats[2 * (row0 + r) + 1] = rstd; }
+    }
+  }
+}
+
 // XCD-aware bijective remap of a linear block id (8 XCDs, round-robin dispatch): blocks that are
 // neighbours after the remap share an XCD (and its L2).  Speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {

@@ -44,6 +44,7 @@ template <typename T>
 struct FfnArgs {
   const T* A; const T* W1; const T* W2; T* H; T* C; const float* bias1; const float* bias2; const T* gate; const T* residual;
   const unsigned long long* bits_in; unsigned long long* bits_out;
+  const float* ln_gamma; const float* ln_beta; T* LN_OUT; float* ln_stats;   // LNF: y = LayerNorm(C) in the final epilogue
   const eg_step_state* st;
   long long lda, ldh, ldc, ldg, ldr;
   int M, F, relu, res_in_lds;
@@ -65,7 +66,8 @@ template <typename T> __device__ __forceinline__ u32x2 f_pack4(const float v[4])
 
 // EPI selects epilogue 1's bias / ReLU at compile time: 3 = bias + ReLU (the forward pass), 0 = neither (the backward pass),
 // 4 = as the descriptor says at run time (a per-value select on the flag -- 80 extra vector instructions per chunk).
-template <typename T, int GATE, int BOUT, int EPI>
+// LNF: the layer's second LayerNorm runs on the completed C rows in the final epilogue (eg_epilogue_layernorm256).
+template <typename T, int GATE, int BOUT, int EPI, bool LNF = false>
 __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   typedef typename H16<T>::frag frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -320,6 +322,13 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
       eraw[i][1] = *(const u32x4*)(pe + 8);
     }
   }
+  float vv[LNF ? 5 : 1][16];                       // LNF: the stored C values of this lane's rows, for the LayerNorm below
+  if (LNF) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) vv[i][j] = 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const int m = m0 + 16 * i + er;
@@ -351,8 +360,15 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
       T* pc = p.C + (size_t)m * (size_t)p.ldc + n;
       store8(pc, v);
       store8(pc + 8, v + 8);
+      if (LNF) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) vv[i][j] = round_store<T>(v[j]);
+      }
     }
   }
+  if constexpr (LNF)
+    eg_epilogue_layernorm256<T>(vv, (float*)(hb + 4 * (16 * F_TP * 4)), wn, lane, min(FR, p.M - m0), (size_t)m0, p.ln_gamma, p.ln_beta,
+                                p.LN_OUT, p.ln_stats);
 }
 
 template <typename T>
@@ -369,25 +385,30 @@ static int ffn_launch(const eg_ffn_desc* d, hipStream_t s) {
   p.dc1 = make_drop(d->drop_c1_p, d->drop_c1_site);
   p.dc2 = make_drop(d->drop_c2_p, d->drop_c2_site);
   p.gate_scale = d->gate_scale == 0.f ? 1.0f : d->gate_scale;
+  p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.LN_OUT = (T*)d->ln_out; p.ln_stats = d->ln_stats;
   const dim3 grid((d->M + FR - 1) / FR);
-#define FFN_LAUNCH(G_, B_, E_)                                                                                         \
+#define FFN_LAUNCH(G_, B_, E_, L_)                                                                                     \
   do {                                                                                                                 \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      (void)hipFuncSetAttribute((const void*)ffn_chain_kernel<T, G_, B_, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS); \
+      (void)hipFuncSetAttribute((const void*)ffn_chain_kernel<T, G_, B_, E_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS); \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((ffn_chain_kernel<T, G_, B_, E_>), grid, dim3(256), F_LDS, s, p);                               \
+    hipLaunchKernelGGL((ffn_chain_kernel<T, G_, B_, E_, L_>), grid, dim3(256), F_LDS, s, p);                           \
   } while (0)
   const int gsel = d->gate_bits_in ? 2 : d->gate ? 1 : 0;
   const bool bout = d->gate_bits_out != nullptr;
-  if (gsel == 0 && d->bias1 && p.relu) { if (bout) FFN_LAUNCH(0, 1, 3); else FFN_LAUNCH(0, 0, 3); }          // the forward pass
-  else if (gsel == 2 && !d->bias1 && !p.relu) FFN_LAUNCH(2, 0, 0);                                           // the backward pass
-  else if (gsel == 1 && !d->bias1 && !p.relu) FFN_LAUNCH(1, 0, 0);
-  else if (gsel == 2) FFN_LAUNCH(2, 0, 4);                                                                    // anything else
-  else if (gsel == 1) FFN_LAUNCH(1, 0, 4);
-  else if (bout) FFN_LAUNCH(0, 1, 4);
-  else FFN_LAUNCH(0, 0, 4);
+  const bool lnf = d->ln_out != nullptr;                                                                      // (forward form only, checked below)
+  if (gsel == 0 && d->bias1 && p.relu) {                                                                      // the forward pass
+    if (lnf) { if (bout) FFN_LAUNCH(0, 1, 3, true); else FFN_LAUNCH(0, 0, 3, true); }
+    else { if (bout) FFN_LAUNCH(0, 1, 3, false); else FFN_LAUNCH(0, 0, 3, false); }
+  }
+  else if (gsel == 2 && !d->bias1 && !p.relu) FFN_LAUNCH(2, 0, 0, false);                                    // the backward pass
+  else if (gsel == 1 && !d->bias1 && !p.relu) FFN_LAUNCH(1, 0, 0, false);
+  else if (gsel == 2) FFN_LAUNCH(2, 0, 4, false);                                                             // anything else
+  else if (gsel == 1) FFN_LAUNCH(1, 0, 4, false);
+  else if (bout) FFN_LAUNCH(0, 1, 4, false);
+  else FFN_LAUNCH(0, 0, 4, false);
 #undef FFN_LAUNCH
   EG_LAUNCH_CHECK("ffn_chain");
   return 0;
@@ -407,6 +428,9 @@ extern "C" int eg_ffn_chain(const eg_ffn_desc* d, void* stream) {
   EG_CHECK(((uintptr_t)d->gate_bits_in | (uintptr_t)d->gate_bits_out) % 8 == 0, "eg_ffn_chain: gate bit words must be 8-B aligned");
   EG_CHECK(!d->residual || (d->ldr >= FD && d->ldr % 8 == 0), "eg_ffn_chain: residual stride");
   EG_CHECK((long long)d->M * d->F < (1ll << 32), "eg_ffn_chain: M*F exceeds the 32-bit dropout index");
+  EG_CHECK(!d->ln_out || (d->ln_gamma && d->ln_beta && d->ldc == FD && !d->gate && !d->gate_bits_in && d->bias1 && d->act1 == EG_ACT_RELU &&
+                          (uintptr_t)d->ln_out % 16 == 0),
+           "eg_ffn_chain: the fused LayerNorm serves the forward form (bias + ReLU, no gate) with contiguous C rows");
   const float ps[3] = {d->drop_h_p, d->drop_c1_p, d->drop_c2_p};
   for (float q : ps) EG_CHECK(q >= 0.f && q < 1.f, "eg_ffn_chain: dropout p");
   EG_CHECK((ps[0] == 0.f && ps[1] == 0.f && ps[2] == 0.f) || d->state, "eg_ffn_chain: dropout needs a step state");

@@ -174,6 +174,10 @@ class Engine:
         self.probe_all = None  # list of (start, end, flops) for every gemm_nt launch when bench.py enables it
         self.attn_block = bool(self._want_attn_block and dtype != EG_F32
                                and L.lib().eg_attn_block_ok(self.S, cfg.d_model, cfg.num_heads, dtype))
+        # the two LayerNorms of an encoder layer as the tail of the launches that complete their input rows (eg_attn_block_fwd ->
+        # norm1, eg_ffn_chain forward -> norm2) instead of two launches that re-read them; the statistics are summed in another order
+        # than eg_layernorm_fwd's, so the step agrees with EYEGAZE_LN_FUSE=0 to rounding, not bit for bit
+        self.ln_fuse = os.environ.get("EYEGAZE_LN_FUSE", "1") != "0"
         self._alloc()
         self.packed_version = -1
         self._recording = False
@@ -374,7 +378,7 @@ class Engine:
         M, d = self.M, self.cfg.d_model
         self.gemm(ptr(x), ptr(self.w[f"qkv{l}"]), ptr(self.a[f"qkv{l}"]), M, 3 * d, d, bias=ptr(self.w[f"bqkv{l}"]))
 
-    def attn_block_fwd(self, x, l, p, sites):
+    def attn_block_fwd(self, x, l, p, sites, ln=None):
         """eg_attn_block_fwd (csrc/attnblock.hip): A:202-213 + the residual of A:292-293 for encoder layer l in one launch"""
         a, w, fp, d = self.a, self.w, self.fp, self.cfg.d_model
         dsc = L.AttnBlockDesc()
@@ -385,6 +389,9 @@ class Engine:
         dsc.NB, dsc.S, dsc.d_model, dsc.num_heads, dsc.dtype = self.NB, self.S, d, self.cfg.num_heads, self.dtype
         dsc.attn_drop_p, dsc.attn_drop_site = p, sites["attn"]
         dsc.out_drop_p, dsc.out_drop_site = p, sites["drop1"]
+        if ln is not None:                  # (gain name, output rows, statistics): norm1 in the same launch
+            dsc.ln_gamma, dsc.ln_beta = fp.p_ptr(ln[0] + ".weight"), fp.p_ptr(ln[0] + ".bias")
+            dsc.ln_out, dsc.ln_stats = ptr(ln[1]), ptr(ln[2])
         probe = None
         if self.probe_all is not None:      # bench.py: timed like the eg_gemm_nt launches, as its own kernel (route 8)
             probe = self._probe_pair()
@@ -406,7 +413,7 @@ class Engine:
         return (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
     def ffn(self, A, W1f, W2f, H, Cout, M, F, *, bias1=0, bias2=0, act1=0, residual=0, gate=0, bits_out=0, bits_in=0,
-            drop_h=(0.0, 0), drop_c1=(0.0, 0), drop_c2=(0.0, 0), gate_scale=1.0):
+            drop_h=(0.0, 0), drop_c1=(0.0, 0), drop_c2=(0.0, 0), gate_scale=1.0, ln=None):
         """eg_ffn_chain: H = epi1(A W1^T), C = epi2(H W2^T) in one launch (weights in fragment order)."""
         d = self.cfg.d_model
         dsc = L.FfnDesc()
@@ -420,6 +427,9 @@ class Engine:
         dsc.drop_c1_p, dsc.drop_c1_site = drop_c1
         dsc.drop_c2_p, dsc.drop_c2_site = drop_c2
         dsc.gate_scale = gate_scale
+        if ln is not None:                  # (gain name, output rows, statistics): norm2 in the same launch
+            dsc.ln_gamma, dsc.ln_beta = self.fp.p_ptr(ln[0] + ".weight"), self.fp.p_ptr(ln[0] + ".bias")
+            dsc.ln_out, dsc.ln_stats = ptr(ln[1]), ptr(ln[2])
         probe = None
         if self.probe_all is not None:      # bench.py: timed like the eg_gemm_nt launches, as its own kernel (route 4)
             probe = self._probe_pair()
@@ -805,7 +815,7 @@ class Engine:
             pre, sites = f"encoder.layers.{l}.", _layer_sites(l)
             x = a[f"x{l}"]
             if self.attn_block:     # q|k|v projection + attention core + out-proj / dropout / residual: one launch, a workgroup per window
-                self.attn_block_fwd(x, l, p, sites)
+                self.attn_block_fwd(x, l, p, sites, ln=((pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"]) if self.ln_fuse else None))
                 self._probs_hook(self.model.encoder.layers[l].mha.dropout, a[f"qkv{l}"], a[f"lse{l}"], 0)
             else:
                 self.qkv_proj(x, l)
@@ -814,18 +824,21 @@ class Engine:
                 self._probs_hook(self.model.encoder.layers[l].mha.dropout, a[f"qkv{l}"], a[f"lse{l}"], 0)
                 self.gemm(ptr(a[f"ctx{l}"]), ptr(w[f"o{l}"]), ptr(a[f"r1_{l}"]), M, d, d, bias=fp.p_ptr(pre + "mha.out_proj.bias"),
                           drop1=(p, sites["drop1"]), residual=ptr(x))
-            self.ln_fwd(a[f"r1_{l}"], pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"])
+            if not (self.attn_block and self.ln_fuse):
+                self.ln_fwd(a[f"r1_{l}"], pre + "ln1", a[f"y1_{l}"], a[f"st1_{l}"])
             if self.fuse_ffn:       # linear1 -> ReLU -> dropout -> linear2 -> dropout x2 -> + residual in one launch (A:272, A:294)
                 self.ffn(ptr(a[f"y1_{l}"]), ptr(w[f"w1f{l}"]), ptr(w[f"w2f{l}"]), ptr(a[f"hff{l}"]), ptr(a[f"r2_{l}"]), M, F,
                          bias1=fp.p_ptr(pre + "ffn.linear1.bias"), bias2=fp.p_ptr(pre + "ffn.linear2.bias"), act1=L.ACT_RELU,
                          residual=ptr(a[f"y1_{l}"]), drop_h=(p, sites["ffn_a"]), drop_c1=(p, sites["ffn_b"]),
-                         drop_c2=(p, sites["drop2"]), bits_out=ptr(a[f"gbits{l}"]))
+                         drop_c2=(p, sites["drop2"]), bits_out=ptr(a[f"gbits{l}"]),
+                         ln=((pre + "ln2", a[f"x{l + 1}"], a[f"st2_{l}"]) if self.ln_fuse else None))
             else:
                 self.gemm(ptr(a[f"y1_{l}"]), ptr(w[f"w1{l}"]), ptr(a[f"hff{l}"]), M, F, d, bias=fp.p_ptr(pre + "ffn.linear1.bias"),
                           act=L.ACT_RELU, drop1=(p, sites["ffn_a"]))
                 self.gemm(ptr(a[f"hff{l}"]), ptr(w[f"w2{l}"]), ptr(a[f"r2_{l}"]), M, d, F, bias=fp.p_ptr(pre + "ffn.linear2.bias"),
                           drop1=(p, sites["ffn_b"]), drop2=(p, sites["drop2"]), residual=ptr(a[f"y1_{l}"]))
-            self.ln_fwd(a[f"r2_{l}"], pre + "ln2", a[f"x{l + 1}"], a[f"st2_{l}"])
+            if not (self.fuse_ffn and self.ln_fuse):
+                self.ln_fwd(a[f"r2_{l}"], pre + "ln2", a[f"x{l + 1}"], a[f"st2_{l}"])
         Lr = cfg.num_layers
         self.ln_fwd(a[f"x{Lr}"], "encoder.norm", a["zn"], a["stf"])
         z = a["zn"]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define EG_ABI_VERSION 4
+#define EG_ABI_VERSION 5
 enum { EG_F32 = 0, EG_BF16 = 1, EG_F16 = 2 };
 enum { EG_ACT_NONE = 0, EG_ACT_RELU = 1, EG_ACT_GELU = 2 };
 
@@ -182,6 +182,12 @@ typedef struct eg_ffn_desc {
   float drop_h_p, drop_c1_p, drop_c2_p;
   uint32_t drop_h_site, drop_c1_site, drop_c2_site;
   float gate_scale;
+  /* optional (forward): the layer's second LayerNorm (A:295, norm2) on the completed C rows, in the same launch:
+   * ln_out = LayerNorm(C) * gamma + beta, ln_stats as eg_layernorm_fwd's.  NULL ln_out = off; needs ldc == 256. */
+  const float* ln_gamma;
+  const float* ln_beta;
+  void* ln_out;         /* out [M, 256] contiguous */
+  float* ln_stats;      /* out [M, 2] or NULL */
 } eg_ffn_desc;
 int eg_ffn_chain(const eg_ffn_desc* d, void* stream);
 int64_t eg_ffn_gate_bits_bytes(int M, int F);
@@ -209,6 +215,12 @@ typedef struct eg_attn_block_desc {
   int32_t NB, S, d_model, num_heads, dtype;
   float attn_drop_p, out_drop_p;
   uint32_t attn_drop_site, out_drop_site;
+  /* optional: the layer's first LayerNorm (A:293, norm1 of the post-LN layer) on the completed rows, in the same launch:
+   * ln_out = LayerNorm(r1) * gamma + beta, ln_stats[2 m] = mean, [2 m + 1] = rstd (what eg_layernorm_fwd writes).  NULL ln_out = off. */
+  const float* ln_gamma;
+  const float* ln_beta;
+  void* ln_out;           /* out [NB*S, 256] */
+  float* ln_stats;        /* out [NB*S, 2] or NULL */
 } eg_attn_block_desc;
 int eg_attn_block_fwd(const eg_attn_block_desc* d, void* stream);
 int eg_attn_block_ok(int S, int d_model, int num_heads, int dtype);   /* 1 when eg_attn_block_fwd serves this geometry */

@@ -1,7 +1,7 @@
 """Diagnostic builds with in-kernel s_memtime stamps (NOT part of the product: they are generated from the product sources into
 scratch/, built into scratch/libstamp_*.so and loaded by pointing eyegaze_multimodal_amd._lib.LIB_PATH at them).
   python profiles/tools/diag/stamp_builds.py build          # on the build box (hipcc, no GPU needed)
-  python profiles/tools/diag/stamp_builds.py run-ffn|run-wide   # on the MI355X
+  python profiles/tools/diag/stamp_builds.py run-ffn|run-wide|run-attn   # on the MI355X
 The stamps are per wave and relative to the wave's own start (s_memtime bases differ between XCDs); every stamp is
 `s_memtime; s_waitcnt lgkmcnt(0)` fenced by sched_barriers (cdna_hip_programming.md, In-kernel stamps)."""
 import subprocess
@@ -59,12 +59,35 @@ extern "C" int eg_debug_stamps(void* out) { return (int)hipMemcpyFromSymbol(out,
     (SCR / "widegemm_stamp.hip").write_text(s)
 
 
+def gen_attn():
+    s = (CS / "attention.hip").read_text()
+    s = rep(s, '#include "common.h"', """#include "../eyegaze_multimodal_amd/csrc/common.h"
+__device__ unsigned long long eg_stamps[2048][4][8];
+#define STAMPV(v_) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(v_) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int eg_debug_stamps(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eg_stamps), sizeof(eg_stamps)); }
+""")
+    k0 = s.index("void attn_bwd1_kernel(")
+    head, body = s[:k0], s[k0:]
+    body = rep(body, "  constexpr int NKT = SP / 16;\n", "  constexpr int NKT = SP / 16;\n  unsigned long long T0, T1, T2, T3, T4, T5;\n  STAMPV(T0);\n")
+    body = rep(body, "  if (qd < SP) {\n    float dsum = 0.f;", "  STAMPV(T5);\n  if (qd < SP) {\n    float dsum = 0.f;")
+    body = rep(body, "  const uint32_t Sp2 = (uint32_t)((S + 1) & ~1);\n  __syncthreads();\n", "  const uint32_t Sp2 = (uint32_t)((S + 1) & ~1);\n  __syncthreads();\n  STAMPV(T1);\n")
+    body = rep(body, "  // ---- dQ: role 0 finishes query tiles [0, NKT/2), role 1 the rest; each hands the other its partial of the other's tiles ----\n  __syncthreads();", "  STAMPV(T2);\n  __syncthreads();\n  STAMPV(T3);")
+    e0 = body.index("// ------------------------------------------------------------------------------------------------\n// Exact-fp32 attention")
+    k_end = body.rindex("}\n", 0, e0)
+    body = body[:k_end] + """  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMPV(T4);
+  if (lane == 0 && blockIdx.x < 2048) { unsigned long long* o = eg_stamps[blockIdx.x][wave];
+    o[0] = T5 - T0; o[1] = T1 - T5; o[2] = T2 - T1; o[3] = T3 - T2; o[4] = T4 - T3; o[5] = T4 - T0; }
+""" + body[k_end:]
+    (SCR / "attention_stamp.hip").write_text(head + body)
+
+
 def build():
     SCR.mkdir(exist_ok=True)
     gen_ffn()
     gen_wide()
+    gen_attn()
     objs = sorted(str(o) for o in CS.glob("*.o"))
-    for name, repl in (("ffn_stamp", "ffn.o"), ("widegemm_stamp", "widegemm.o")):
+    for name, repl in (("ffn_stamp", "ffn.o"), ("widegemm_stamp", "widegemm.o"), ("attention_stamp", "attention.o")):
         subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-I", str(ROOT / "include"), "-c",
                         str(SCR / f"{name}.hip"), "-o", str(SCR / f"{name}.o")], check=True)
         subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(SCR / f"lib{name}.so"), str(SCR / f"{name}.o"),
@@ -127,5 +150,37 @@ def run_wide():
             print(f"   {names[i]:26s} median {int(np.median(col)):7d}  p10 {int(np.percentile(col, 10)):7d}  p90 {int(np.percentile(col, 90)):7d}")
 
 
+def run_attn():
+    import ctypes as C
+    sys.path.insert(0, str(ROOT))
+    from eyegaze_multimodal_amd import _lib as L
+    L.LIB_PATH = (SCR / "libattention_stamp.so").resolve()
+    import numpy as np
+    import torch
+    from eyegaze_multimodal_amd._lib import call, ptr
+    from tests.test_gpu_ops import DEV, dev_state
+    NB, S, H, D = 512, 65, 8, 256
+    g = torch.Generator().manual_seed(3)
+    qkv = (torch.randn(NB * S, 3 * D, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    ctx = torch.zeros(NB * S, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(NB, H, S, device=DEV)
+    st = dev_state(seed=5)
+    call("eg_attention_fwd", ptr(qkv), ptr(ctx), ptr(lse), NB, S, H, 0, L.EG_BF16, 0.1, 21, ptr(st), 0)
+    dctx = (torch.randn(NB * S, D, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    dqkv = torch.zeros_like(qkv)
+    for _ in range(3):
+        call("eg_attention_bwd", ptr(qkv), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), NB, S, H, 0, L.EG_BF16, 0.1, 21, ptr(st), 0)
+        torch.cuda.synchronize()
+    buf = np.zeros((2048, 4, 8), dtype=np.uint64)
+    L.lib().eg_debug_stamps(C.c_void_p(buf.ctypes.data))
+    t = buf.astype(np.int64)
+    names = ["request everything, store q, k, dO images", "delta = rowsum(dO * O), barrier", "key-tile loop", "wait at the exchange barrier", "dQ exchange + stores drained", "lifetime"]
+    for role in (0, 1):
+        print(f"attn_bwd1 NB={NB} S={S} p=0.1, waves of role {role} (key tiles {'0, 2, 4' if role == 0 else '1, 3'}): cycles per wave")
+        for i, n in enumerate(names):
+            col = t[:, role::2, i]
+            print(f"   {n:44s} median {int(np.median(col)):7d}  p10 {int(np.percentile(col, 10)):7d}  p90 {int(np.percentile(col, 90)):7d}")
+
+
 if __name__ == "__main__":
-    {"build": build, "run-ffn": run_ffn, "run-wide": run_wide}[sys.argv[1]]()
+    {"build": build, "run-ffn": run_ffn, "run-wide": run_wide, "run-attn": run_attn}[sys.argv[1]]()

@@ -25,7 +25,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     lib.eg_abi_version.restype = ctypes.c_int
-    assert lib.eg_abi_version() == 4
+    assert lib.eg_abi_version() == 5
 
 
 def test_binding_covers_the_header():

@@ -123,6 +123,7 @@ def test_training_step_is_bit_identical_with_and_without_the_block(name, dtype, 
     from tests.helpers import t
     from tests.test_gpu_model import build
     res = {}
+    monkeypatch.setenv("EYEGAZE_LN_FUSE", "0")       # (the fused LayerNorm sums its statistics in another order: tests/test_gpu_lnfuse.py)
     for flag in ("1", "0"):
         monkeypatch.setenv("EYEGAZE_ATTN_BLOCK", flag)
         z, kw, cfg, sd, model = build(name, dtype)

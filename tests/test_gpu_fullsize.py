@@ -152,6 +152,7 @@ def test_fresh_models_at_full_size_with_and_without_the_attention_block(dtype, m
     full size, with the window-resident attention block off and on -- outputs must be finite, deterministic and bit-identical
     between the two (the block replaces three launches bit for bit)."""
     outs = {}
+    monkeypatch.setenv("EYEGAZE_LN_FUSE", "0")       # bit-identity holds for the block itself; the fused LayerNorm is tests/test_gpu_lnfuse.py's
     for flag in ("0", "1", "1", "0", "1"):
         monkeypatch.setenv("EYEGAZE_ATTN_BLOCK", flag)
         z, kw, cfg, sd, model = build("cfg3_xattn", dtype)
