@@ -121,25 +121,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   }
   uint32_t seed_lo = 0, seed_hi = 0;
   if (dc.thresh) { seed_lo = st->seed_lo; seed_hi = st->seed_hi; }
-  // A LAST key tile with a single valid key (S = 16 n + 1: a class token in front of 16 n positions) evaluates ONE accumulator
-  // register per lane instead of four: the scale / max / exp / normalise / dropout chain is the kernel's bound (vector issue, not
-  // the matrix pipe), and the three masked registers are zero probabilities whatever is computed for them.  Same values, bit for bit.
-  const int ktail = ((S & 15) == 1) ? nkt - 1 : -1;
-  // every query tile's fragment is requested before the loop (the load sat in front of each tile's first MFMA)
-  FR<T> qfs[(NKT + 1) / 2];
-#pragma unroll
-  for (int i = 0; i < (NKT + 1) / 2; ++i) {
-    const int q = (role + 2 * i) * 16 + l15;
-    qfs[i] = ld_frag_global<T>(qbase + (long long)q * ld + g * 8, q < S && role + 2 * i < nkt);
-  }
   rows_store<NCH>(vimg, rv, SP, lane + 64 * role);
   __syncthreads();
-#pragma unroll
-  for (int qi = 0; qi < (NKT + 1) / 2; ++qi) {
-    const int qt = role + 2 * qi;
-    if (qt >= nkt) break;
+  // (Requesting every query tile's fragment before the loop, unrolling it, and a one-register tail key tile for S = 16 n + 1 were
+  // measured on this kernel too: 52.9 -> 65.7 us at SP = 128, 69.3 -> 84.4 us at SP = 160, 27.7 -> 30.4 us at SP = 96 -- more registers,
+  // one wave per SIMD fewer.  Only the batched prologue stayed.)
+  for (int qt = role; qt < nkt; qt += 2) {
     const int q = qt * 16 + l15;
-    const FR<T> qf = qfs[qi];
+    const FR<T> qf = ld_frag_global<T>(qbase + (long long)q * ld + g * 8, q < S);
     f32x4 s[NKT];
     float mx = -INFINITY;
 #pragma unroll
@@ -147,18 +136,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
       s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (kt < nkt) {   // wave-uniform: key tiles beyond the sequence cost nothing (S = 65 uses 5 of the 6 tiles)
         s[kt] = H16<T>::mfma(kf[kt], qf, s[kt]);
-        if (kt == ktail) {
-          const float v = g == 0 ? s[kt][0] * kScale : -INFINITY;
-          s[kt][0] = v;
-          mx = fmaxf(mx, v);
-        } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kt * 16 + 4 * g + r;
-            const float v = key < S ? s[kt][r] * kScale : -INFINITY;
-            s[kt][r] = v;
-            mx = fmaxf(mx, v);
-          }
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * g + r;
+          const float v = key < S ? s[kt][r] * kScale : -INFINITY;
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
         }
       }
     }
@@ -168,17 +151,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if (kt < nkt) {
-        if (kt == ktail) {
-          const float p = __expf(s[kt][0] - mx);
-          s[kt] = (f32x4){p, 0.f, 0.f, 0.f};
-          sum += p;
-        } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = __expf(s[kt][r] - mx);
-            s[kt][r] = p;
-            sum += p;
-          }
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(s[kt][r] - mx);
+          s[kt][r] = p;
+          sum += p;
         }
       }
     }
@@ -190,16 +167,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if (kt < nkt) {
-        if (kt == ktail) {
-          s[kt][0] = eg_dropout(s[kt][0] * inv, dc, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g));
-        } else {
-          float pv[4];
+        float pv[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pv[r] = s[kt][r] * inv;
-          eg_dropout_run<4>(pv, dc, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g));
+        for (int r = 0; r < 4; ++r) pv[r] = s[kt][r] * inv;
+        eg_dropout_run<4>(pv, dc, seed_lo, seed_hi, rowidx + (uint32_t)(kt * 16 + 4 * g));
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[kt][r] = pv[r];
-        }
+        for (int r = 0; r < 4; ++r) s[kt][r] = pv[r];
       }
     }
     f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};

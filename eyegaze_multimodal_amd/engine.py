@@ -398,6 +398,8 @@ class Engine:
             M, S, H = self.M, self.S, self.cfg.num_heads
             flops = 2.0 * M * d * 3 * d + 2.0 * M * d * d + 4.0 * self.NB * H * S * S * (d // H)
             nbytes = self.es * (M * d * 3 + M * 3 * d + 4 * d * d) + 4 * (self.NB * H * S + 4 * d)    # x, ctx, r1 | qkv | weights | lse, biases
+            if ln is not None:
+                nbytes += self.es * M * d + 8 * M + 8 * d                                             # norm1 rows, statistics, gain / bias
             self.probe_all.append((probe[0], probe[1], flops, float(nbytes), (M, 3 * d, d), 8))
             probe[0].record(torch.cuda.current_stream(self.device))
         call("eg_attn_block_fwd", C.byref(dsc), self.stream)
@@ -435,7 +437,7 @@ class Engine:
             probe = self._probe_pair()
             es = self.es
             nbytes = es * (M * d * (2 + (1 if residual and residual != A else 0)) + M * F * (1 + (1 if gate else 0)) + 2 * F * d) \
-                + (M * F // 8 if (bits_out or bits_in) else 0) + 4 * (F + d)
+                + (M * F // 8 if (bits_out or bits_in) else 0) + 4 * (F + d) + ((es * M * d + 8 * M + 8 * d) if ln is not None else 0)
             self.probe_all.append((probe[0], probe[1], 4.0 * M * F * d, float(nbytes), (M, F, d), 4))
             probe[0].record(torch.cuda.current_stream(self.device))
         call("eg_ffn_chain", C.byref(dsc), self.stream)
