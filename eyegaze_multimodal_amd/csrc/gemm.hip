@@ -768,43 +768,44 @@ __global__ __launch_bounds__(1024) void unpack_conv_wgrad_kernel(const float* __
 }
 
 // column sums of a [M, N] matrix: block b sums rows [b*rpb, (b+1)*rpb) -> partial[b, N]
+// A row is N / 8 16-B chunks; the 256 threads are 256 / (N / 8) row lanes x N / 8 chunk lanes, every row lane walks its rows two at a
+// time.  (Until round 3 the map was 8 row lanes x 32 chunk lanes whatever N: at N = 64 -- the spectrogram convolutions -- 24 of 32
+// lanes idled and a block had 8 rows in flight: 235 us per launch at the reference's default C = 32.)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ Y, RowMap y, int M, int N, int rpb,
                                                      float* __restrict__ partial) {
-  __shared__ float red[8][1024 + 8];
-  const int tid = threadIdx.x, cl = tid & 31, rl = tid >> 5;
-  const int nch = N >> 3;
+  __shared__ float red[256][9];
+  const int tid = threadIdx.x;
+  const int cpr = N >> 3;                                    // chunks per row (<= 128)
+  const int nrl = 256 / cpr;                                 // row lanes (>= 2)
+  const int c = tid % cpr, rl = tid / cpr;
   const int mbeg = blockIdx.x * rpb, mend = min(M, mbeg + rpb);
-  float acc[4][8];
+  float acc[8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (rl < nrl) {
+    int m = mbeg + rl;
+    for (; m + nrl < mend; m += 2 * nrl) {
+      float v0[8], v1[8];
+      load8(Y + row_off(y, m) + c * 8, v0);
+      load8(Y + row_off(y, m + nrl) + c * 8, v1);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
-  for (int m = mbeg + rl; m < mend; m += 8) {
-    const T* row = Y + row_off(y, m);
+      for (int e = 0; e < 8; ++e) { acc[e] += v0[e]; acc[e] += v1[e]; }
+    }
+    if (m < mend) {
+      float v0[8];
+      load8(Y + row_off(y, m) + c * 8, v0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = cl + 32 * j;
-      if (c < nch) {
-        float v[8];
-        load8(row + c * 8, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[j][e] += v[e];
-      }
+      for (int e = 0; e < 8; ++e) acc[e] += v0[e];
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = cl + 32 * j;
-    if (c < nch)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) red[rl][c * 8 + e] = acc[j][e];
-  }
+  for (int e = 0; e < 8; ++e) red[tid][e] = acc[e];
   __syncthreads();
   for (int n = tid; n < N; n += 256) {
+    const int cc = n >> 3, e = n & 7;
     float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) s += red[r][n];
+    for (int r = 0; r < nrl; ++r) s += red[r * cpr + cc][e];
     partial[(size_t)blockIdx.x * N + n] = s;
   }
 }
@@ -964,6 +965,17 @@ extern "C" int eg_reduce_partials(float* partial, float* out, int64_t n, int spl
                      (hipStream_t)stream, partial, out, (long long)n, splits, (long long)split_stride, accumulate, 0);
   EG_LAUNCH_CHECK("reduce_partials");
   return 0;
+}
+
+// First stage of a long split reduction for other files (spec.hip): groups of `group` consecutive splits are summed IN PLACE into each
+// group's first slab (the partial buffer is scratch); the caller then reads ceil(splits / group) slabs at stride `stride * group`.
+int eg_reduce_groups_inplace(float* partial, long long n, int splits, long long stride, int groups, int* group_out, hipStream_t s) {
+  const int group = (splits + groups - 1) / groups;
+  const unsigned gx = (unsigned)((n + 31) / 32);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, (unsigned)((splits + group - 1) / group)), dim3(256), 0, s, partial, partial, n,
+                     splits, stride, 0, group);
+  *group_out = group;
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 extern "C" int eg_unpack_conv_wgrad(const float* partial, float* dW, int splits, int N, int Cin, int k, int Cp, int Kp,

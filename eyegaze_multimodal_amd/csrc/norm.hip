@@ -191,33 +191,39 @@ __global__ __launch_bounds__(256) void layernorm_bwd256_kernel(const T* __restri
   // both halves of a wave must run the same trip count (the shuffles below are wave-wide)
   const int trips = (M + nrows - 1) / nrows;
   // software pipeline: the next trip's rows are requested before this trip's arithmetic (4 x 16 B in flight per lane)
-  struct Row { float xv[8], dv[8], mean, rstd; };
+  constexpr int NV = (int)sizeof(T) / 2;                     // 16-B vectors per 8 elements
+  struct Row { u32x4 x[NV], d[NV]; float mean, rstd; };      // rows wait as loaded (packed): four of them are in flight per lane
   auto fetch = [&](int it, Row& r) {
     const int row = it * nrows + blockIdx.x * 8 + hw;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { r.xv[e] = 0.f; r.dv[e] = 0.f; }
+    for (int v = 0; v < NV; ++v) { r.x[v] = (u32x4){0u, 0u, 0u, 0u}; r.d[v] = (u32x4){0u, 0u, 0u, 0u}; }
     r.mean = 0.f; r.rstd = 0.f;
     if (it < trips && row < M) {
-      load8(x + (size_t)row * 256 + l * 8, r.xv);
-      load8(dy + (size_t)row * 256 + l * 8, r.dv);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        r.x[v] = *(const u32x4*)((const char*)(x + (size_t)row * 256 + l * 8) + 16 * v);
+        r.d[v] = *(const u32x4*)((const char*)(dy + (size_t)row * 256 + l * 8) + 16 * v);
+      }
       r.mean = stats[2 * row];
       r.rstd = stats[2 * row + 1];
     }
   };
-  Row cur, nxt;
-  fetch(0, cur);
-  for (int it = 0; it < trips; ++it) {
-    fetch(it + 1, nxt);
+  // TWO trips' rows are in flight (8 x 16 B per lane): a block walks four trips at the benchmark size, and with one trip ahead the
+  // launch was a chain of five HBM latencies (17 us for 68 MB); the rows are still consumed in trip order (same sums)
+  auto consume = [&](int it, const Row& cur) {
     const int row = it * nrows + blockIdx.x * 8 + hw;
     const bool ok = row < M;
     const float mean = cur.mean, rstd = cur.rstd;
+    float xv[8], dv[8];
+    load8((const T*)&cur.x[0], xv);
+    load8((const T*)&cur.d[0], dv);
     float xh[8], s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      xh[e] = (cur.xv[e] - mean) * rstd;
-      dg[e] += cur.dv[e] * xh[e];
-      db[e] += cur.dv[e];
-      const float dxh = cur.dv[e] * g[e];
+      xh[e] = (xv[e] - mean) * rstd;
+      dg[e] += dv[e] * xh[e];
+      db[e] += dv[e];
+      const float dxh = dv[e] * g[e];
       s1 += dxh;
       s2 += dxh * xh[e];
     }
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd256_kernel(const T* __restri
     if (ok) {
       float o[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = rstd * (cur.dv[e] * g[e] - c1 - xh[e] * c2);
+      for (int e = 0; e < 8; ++e) o[e] = rstd * (dv[e] * g[e] - c1 - xh[e] * c2);
       store8(dx + (size_t)row * 256 + l * 8, o);
       if (dx_drop) {
         if (drop) {
@@ -236,7 +242,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd256_kernel(const T* __restri
         store8(dx_drop + (size_t)row * 256 + l * 8, o);
       }
     }
-    cur = nxt;
+  };
+  Row ra, rb, rc, rd;
+  fetch(0, ra);
+  fetch(1, rb);
+  for (int it = 0; it < trips; it += 2) {
+    fetch(it + 2, rc);
+    fetch(it + 3, rd);
+    consume(it, ra);
+    if (it + 1 < trips) consume(it + 1, rb);
+    ra = rc;
+    rb = rd;
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {

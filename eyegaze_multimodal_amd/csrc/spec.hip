@@ -165,16 +165,26 @@ __global__ void pack_conv2d_weight_kernel(const float* __restrict__ w, T* __rest
   Elem<T>::st(dst + i, v);
 }
 
-// dW[n][c][ky][kx] = sum_s partial[s][n][(ky*4 + kx)*Cin + c]
-__global__ void unpack_conv2d_wgrad_kernel(const float* __restrict__ partial, float* __restrict__ dW, int splits, int N,
-                                           int Cin) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)N * Cin * 9) return;
-  const int kx = (int)(i % 3), ky = (int)((i / 3) % 3), c = (int)((i / 9) % Cin), n = (int)(i / (9 * Cin));
+// dW[n][c][ky][kx] = sum_s partial[s][n][(ky*4 + kx)*Cin + c].  Thread <-> one element of a [N][12 * Cin] slab, c fastest, so a wave
+// reads 256 contiguous bytes of every slab (the former map walked (kx, ky, c): 4-B reads Cin floats apart, 72 blocks streaming up to
+// 768 slabs: 81 us per launch); four slabs are requested per trip, the sums keep their order.
+__global__ __launch_bounds__(256) void unpack_conv2d_wgrad_kernel(const float* __restrict__ partial, float* __restrict__ dW, int splits,
+                                                                  long long stride, int N, int Cin) {
   const int K = 12 * Cin;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)N * K) return;
+  const int n = (int)(i / K), r = (int)(i % K), kk = r / Cin, c = r % Cin, ky = kk >> 2, kx = kk & 3;
+  if (kx == 3) return;                                       // pad tap of the 3 x 4 window
+  const float* src = partial + i;
   float s = 0.f;
-  for (int sp = 0; sp < splits; ++sp) s += partial[((size_t)sp * N + n) * K + (ky * 4 + kx) * Cin + c];
-  dW[i] = s;
+  int sp = 0;
+  for (; sp + 4 <= splits; sp += 4) {
+    const float a0 = src[(size_t)sp * stride], a1 = src[(size_t)(sp + 1) * stride], a2 = src[(size_t)(sp + 2) * stride],
+                a3 = src[(size_t)(sp + 3) * stride];
+    s += a0; s += a1; s += a2; s += a3;
+  }
+  for (; sp < splits; ++sp) s += src[(size_t)sp * stride];
+  dW[(((size_t)n * Cin + c) * 3 + ky) * 3 + kx] = s;
 }
 
 }  // namespace
@@ -260,11 +270,21 @@ extern "C" int eg_pack_conv2d_weight(const float* w, void* dst, int N, int Cin, 
   return 0;
 }
 
-extern "C" int eg_unpack_conv2d_wgrad(const float* partial, float* dW, int splits, int N, int Cin, void* stream) {
+int eg_reduce_groups_inplace(float* partial, long long n, int splits, long long stride, int groups, int* group_out, hipStream_t s);   // gemm.hip
+
+extern "C" int eg_unpack_conv2d_wgrad(float* partial, float* dW, int splits, int N, int Cin, void* stream) {
   EG_CHECK(partial && dW && splits > 0 && N > 0 && Cin > 0, "eg_unpack_conv2d_wgrad: bad arguments");
-  const long long n = (long long)N * Cin * 9;
-  hipLaunchKernelGGL(unpack_conv2d_wgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial,
-                     dW, splits, N, Cin);
+  const long long slab = (long long)N * 12 * Cin;
+  EG_CHECK(slab % 4 == 0, "eg_unpack_conv2d_wgrad: N * 12 * Cin must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  long long stride = slab;
+  if (splits > 64) {                  // long reductions in two stages: 64 groups of slabs are summed in place first (partial is scratch)
+    int group = 1;
+    if (eg_reduce_groups_inplace(partial, slab, splits, slab, 64, &group, s)) return eg_fail("eg_unpack_conv2d_wgrad: stage-1 launch failed");
+    splits = (splits + group - 1) / group;
+    stride = slab * group;
+  }
+  hipLaunchKernelGGL(unpack_conv2d_wgrad_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, partial, dW, splits, stride, N, Cin);
   EG_LAUNCH_CHECK("unpack_conv2d_wgrad");
   return 0;
 }

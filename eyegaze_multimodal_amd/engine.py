@@ -161,11 +161,13 @@ class Engine:
         # feed-forward pair as one launch (csrc/ffn.hip): 16-bit compute dtypes, d_model == 256, d_ff a multiple of 128
         self.fuse_ffn = (dtype != EG_F32 and cfg.d_model == 256 and cfg.d_ff % 128 == 0
                          and os.environ.get("EYEGAZE_FFN", "1") != "0")
-        # LayerNorm backward: a block walks 8 rows per trip; about a thousand blocks (4 waves per SIMD) whose trip count divides M
-        # evenly -- 33 280 rows: 1040 blocks x 4 trips, against 512 blocks x 8.1 -> 9 trips (measured 3.90 -> 3.87 ms / step)
+        # LayerNorm backward: a block walks 8 rows per trip with TWO trips in flight (112 registers: four 256-thread blocks per CU).
+        # All blocks must be resident at once -- a late block starts when an early one ends and doubles the launch -- so at most
+        # 4 blocks per CU: 33 280 rows = 1024 blocks x 4.06 trips (round 2: 1040 x 4 with one trip in flight)
         env_nb = os.environ.get("EYEGAZE_LN_BLOCKS")
         trips = max(1, self.M // 8192)
-        self.LN_BLOCKS = int(env_nb) if env_nb else min(self.LN_PARTIAL_BLOCKS, max(1, (self.M + 8 * trips - 1) // (8 * trips)))
+        self.LN_BLOCKS = int(env_nb) if env_nb else min(self.LN_PARTIAL_BLOCKS, 4 * self.cus,
+                                                        max(1, (self.M + 8 * trips - 1) // (8 * trips)))
         if not 1 <= self.LN_BLOCKS <= self.LN_PARTIAL_BLOCKS:
             # round 2: a sweep at 2080 blocks stored past the 2048-row partial buffer (GPU memory access fault); refuse, never clamp
             raise L.EgError(f"EYEGAZE_LN_BLOCKS={env_nb} is outside [1, {self.LN_PARTIAL_BLOCKS}] (rows of the LayerNorm-backward "

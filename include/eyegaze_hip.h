@@ -442,7 +442,7 @@ int eg_spec_conv1_bwd(const float* img, const float* w, const float* bias, const
 int eg_spec_avgpool_fwd(const void* out2, void* pooled, int nimg, int Hp, int Wp, int dtype, void* stream);
 int eg_spec_avgpool_bwd(const void* out2, const void* dpooled, void* d2, int nimg, int Hp, int Wp, int dtype, void* stream);
 int eg_pack_conv2d_weight(const float* w, void* dst, int N, int Cin, int transposed, int dtype, void* stream);
-int eg_unpack_conv2d_wgrad(const float* partial, float* dW, int splits, int N, int Cin, void* stream);
+int eg_unpack_conv2d_wgrad(float* partial /* scratch: reduced in place when splits > 64 */, float* dW, int splits, int N, int Cin, void* stream);
 
 #ifdef __cplusplus
 }
