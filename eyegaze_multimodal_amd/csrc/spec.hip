@@ -118,32 +118,60 @@ __global__ __launch_bounds__(256) void spec_conv1_bwd_kernel(const float* __rest
 
 // out2 [Hp+2][Wp][64] (post-ReLU) -> pooled [1024] = (c, py, px), mean over (Hp/4) x (Wp/4) windows
 template <typename T>
-__global__ void spec_avgpool_fwd_kernel(const T* __restrict__ out2, T* __restrict__ pooled, int Hp, int Wp) {
+__global__ __launch_bounds__(128) void spec_avgpool_fwd_kernel(const T* __restrict__ out2, T* __restrict__ pooled, int Hp, int Wp) {
+  // thread <-> (window, 8 channels): 16-B reads, the window's positions summed in the same (y, x) order as the element-per-thread
+  // form it replaces (which moved 2 B per lane: 284 us at C = 32)
   const int im = blockIdx.x, wy = Hp / 4, wx = Wp / 4;
   const T* ib = out2 + (size_t)im * (Hp + 2) * Wp * C2;
-  for (int o = threadIdx.x; o < C2 * 16; o += blockDim.x) {
-    // consecutive threads take consecutive channels (coalesced reads); the store is strided but tiny
-    const int c = o & 63, cell = o >> 6, py = cell >> 2, px = cell & 3;
-    float s = 0.f;
-    for (int y = py * wy; y < (py + 1) * wy; ++y)
-      for (int x = px * wx; x < (px + 1) * wx; ++x) s += Elem<T>::ld(ib + ((size_t)y * Wp + x) * C2 + c);
-    Elem<T>::st(pooled + (size_t)im * (C2 * 16) + c * 16 + py * 4 + px, s / (float)(wy * wx));
+  const int o = threadIdx.x;                                  // 16 windows x 8 channel groups
+  const int c8 = (o & 7) * 8, cell = o >> 3, py = cell >> 2, px = cell & 3;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  for (int y = py * wy; y < (py + 1) * wy; ++y) {
+    const T* row = ib + ((size_t)y * Wp + px * wx) * C2 + c8;
+    int x = 0;
+    for (; x + 2 <= wx; x += 2) {
+      float a[8], b[8];
+      load8(row + (size_t)x * C2, a);
+      load8(row + (size_t)(x + 1) * C2, b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] += a[e]; s[e] += b[e]; }
+    }
+    if (x < wx) {
+      float a[8];
+      load8(row + (size_t)x * C2, a);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += a[e];
+    }
   }
+  const float d = (float)(wy * wx);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) Elem<T>::st(pooled + (size_t)im * (C2 * 16) + (c8 + e) * 16 + py * 4 + px, s[e] / d);
 }
 
 // d2 [Hp+2][Wp+4][64] interior = dpooled / (wy*wx) where out2 > 0
 template <typename T>
-__global__ void spec_avgpool_bwd_kernel(const T* __restrict__ out2, const T* __restrict__ dpooled, T* __restrict__ d2, int Hp,
-                                        int Wp) {
+__global__ __launch_bounds__(256) void spec_avgpool_bwd_kernel(const T* __restrict__ out2, const T* __restrict__ dpooled, T* __restrict__ d2,
+                                                               int Hp, int Wp) {
+  // 16-B accesses (8 channels per thread) with the image's 64 x 16 pooled gradients staged once in LDS as [window][channel]; the
+  // element-per-thread form moved 2 B per lane and re-read the pooled gradient from global memory per element (611 us at C = 32)
+  __shared__ float gs[16][C2 + 4];
   const int im = blockIdx.x, wy = Hp / 4, wx = Wp / 4;
   const T* ob = out2 + (size_t)im * (Hp + 2) * Wp * C2;
   T* db = d2 + (size_t)im * (Hp + 2) * (Wp + 4) * C2;
   const float inv = 1.0f / (float)(wy * wx);
-  for (int i = threadIdx.x; i < Hp * Wp * C2; i += blockDim.x) {
-    const int c = i & 63, x = (i >> 6) % Wp, y = (i >> 6) / Wp;
-    const float g = Elem<T>::ld(dpooled + (size_t)im * (C2 * 16) + c * 16 + (y / wy) * 4 + (x / wx));
-    const float a = Elem<T>::ld(ob + ((size_t)y * Wp + x) * C2 + c);
-    Elem<T>::st(db + ((size_t)(y + 1) * (Wp + 4) + (x + 1)) * C2 + c, a > 0.f ? g * inv : 0.f);
+  for (int j = threadIdx.x; j < C2 * 16; j += blockDim.x)
+    gs[j & 15][j >> 4] = Elem<T>::ld(dpooled + (size_t)im * (C2 * 16) + j) * inv;
+  __syncthreads();
+  for (int i8 = threadIdx.x; i8 < Hp * Wp * (C2 / 8); i8 += blockDim.x) {
+    const int c8 = (i8 & (C2 / 8 - 1)) * 8, xy = i8 / (C2 / 8), x = xy % Wp, y = xy / Wp;
+    const float* g = gs[(y / wy) * 4 + (x / wx)] + c8;
+    float a[8], o[8];
+    load8(ob + ((size_t)y * Wp + x) * C2 + c8, a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = a[e] > 0.f ? g[e] : 0.f;
+    store8(db + ((size_t)(y + 1) * (Wp + 4) + (x + 1)) * C2 + c8, o);
   }
 }
 
@@ -235,9 +263,9 @@ extern "C" int eg_spec_avgpool_fwd(const void* out2, void* pooled, int nimg, int
   EG_CHECK(out2 && pooled && nimg > 0 && Hp % 4 == 0 && Wp % 4 == 0, "eg_spec_avgpool_fwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   SPEC_DISPATCH(dtype,
-                hipLaunchKernelGGL(spec_avgpool_fwd_kernel<bf16_t>, dim3(nimg), dim3(256), 0, s, (const bf16_t*)out2, (bf16_t*)pooled, Hp, Wp),
-                hipLaunchKernelGGL(spec_avgpool_fwd_kernel<f16_t>, dim3(nimg), dim3(256), 0, s, (const f16_t*)out2, (f16_t*)pooled, Hp, Wp),
-                hipLaunchKernelGGL(spec_avgpool_fwd_kernel<float>, dim3(nimg), dim3(256), 0, s, (const float*)out2, (float*)pooled, Hp, Wp),
+                hipLaunchKernelGGL(spec_avgpool_fwd_kernel<bf16_t>, dim3(nimg), dim3(128), 0, s, (const bf16_t*)out2, (bf16_t*)pooled, Hp, Wp),
+                hipLaunchKernelGGL(spec_avgpool_fwd_kernel<f16_t>, dim3(nimg), dim3(128), 0, s, (const f16_t*)out2, (f16_t*)pooled, Hp, Wp),
+                hipLaunchKernelGGL(spec_avgpool_fwd_kernel<float>, dim3(nimg), dim3(128), 0, s, (const float*)out2, (float*)pooled, Hp, Wp),
                 "eg_spec_avgpool_fwd");
   EG_LAUNCH_CHECK("spec_avgpool_fwd");
   return 0;
