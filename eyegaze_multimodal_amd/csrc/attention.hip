@@ -568,35 +568,43 @@ __global__ __launch_bounds__(256, SP <= 96 ? 3 : 2) void attn_bwd1_kernel(const 
   rows_request<T, NCH>(rq, qbase, ld, S, first);
   rows_request<T, NCH>(rk, kbase, ld, S, first);
   rows_request<T, NCH>(rd, dobase, D, S, first);
-  static_assert(SP <= 128, "one delta row per lane");
-  const int qd = first;                                      // (the loop `for (q = first; q < SP; q += 128)` has one trip)
-  u32x4 da[4], oa[4];
-  float lq0 = 0.f;
+  constexpr int NQ = (SP + 127) / 128;                       // delta rows per lane (query first + 128 j)
+  u32x4 da[NQ][4], oa[NQ][4];
+  float lq0[NQ];
 #pragma unroll
-  for (int c4 = 0; c4 < 4; ++c4) { da[c4] = (u32x4){0u, 0u, 0u, 0u}; oa[c4] = (u32x4){0u, 0u, 0u, 0u}; }
-  if (qd < S) {
-    lq0 = lse[((long long)b * H + h) * S + qd];
+  for (int j = 0; j < NQ; ++j) {
+    const int qd = first + 128 * j;
+    lq0[j] = 0.f;
 #pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) {
-      da[c4] = *(const u32x4*)(dobase + (long long)qd * D + c4 * 8);
-      oa[c4] = *(const u32x4*)(obase + (long long)qd * D + c4 * 8);
+    for (int c4 = 0; c4 < 4; ++c4) { da[j][c4] = (u32x4){0u, 0u, 0u, 0u}; oa[j][c4] = (u32x4){0u, 0u, 0u, 0u}; }
+    if (qd < S) {
+      lq0[j] = lse[((long long)b * H + h) * S + qd];
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        da[j][c4] = *(const u32x4*)(dobase + (long long)qd * D + c4 * 8);
+        oa[j][c4] = *(const u32x4*)(obase + (long long)qd * D + c4 * 8);
+      }
     }
   }
   rows_store<NCH>(qimg, rq, SP, first);
   rows_store<NCH>(kimg, rk, SP, first);
   rows_store<NCH>(doimg, rd, SP, first);
-  if (qd < SP) {
-    float dsum = 0.f;
 #pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) {
-      float a[8], o[8];
-      load8((const T*)&da[c4], a);
-      load8((const T*)&oa[c4], o);
+  for (int j = 0; j < NQ; ++j) {
+    const int qd = first + 128 * j;
+    if (qd < SP) {
+      float dsum = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dsum += a[e] * o[e];
+      for (int c4 = 0; c4 < 4; ++c4) {
+        float a[8], o[8];
+        load8((const T*)&da[j][c4], a);
+        load8((const T*)&oa[j][c4], o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += a[e] * o[e];
+      }
+      lsel[qd] = lq0[j];
+      dl[qd] = dsum;
     }
-    lsel[qd] = lq0;
-    dl[qd] = dsum;
   }
   const int nkt = (S + 15) >> 4;        // (run-time also when NKTX names it: the pair loop below keeps one basic block per pair --
                                         //  with a constant count the scheduler hoisted every pair's operand reads and spilled 31 registers)
@@ -797,15 +805,15 @@ int launch_bwd(const void* qkv, const void* ctx, const void* dctx, const float* 
                int kv_shift, DropCfg dc, const eg_step_state* st, hipStream_t s) {
   const int nblk = (NB * H + 1) / 2;
   static const int single = [] { const char* e = getenv("EYEGAZE_ATTN_BWD1"); return e ? atoi(e) : 1; }();
-  // Single sweep (each P / dS block evaluated once; key-major, see attn_bwd1_kernel) for S <= 96: cfg3 step 3.87 -> 3.78 ms, cfg5
-  // 5.63 -> 5.54 ms.  Longer sequences keep the two-pass kernel: at SP = 128 the 8 NKT + 16 accumulator registers leave two waves
-  // per SIMD and the a5 step measured 9.04 against 8.96 ms.  EYEGAZE_ATTN_BWD1=0 forces the two-pass kernel, =2 the single sweep
-  // wherever it is instantiated (S <= 128).
-  if ((SP <= 96 && single) || (SP <= 128 && single == 2)) {
+  // Single sweep (each P / dS block evaluated once; key-major, see attn_bwd1_kernel) for S <= 128: cfg3 step 3.87 -> 3.78 ms, cfg5
+  // 5.63 -> 5.54 ms in round 2.  At SP = 128 it lost then (a5 9.04 vs 8.96 ms) -- with 272 B of scratch per lane nobody had noticed;
+  // since accq stays in registers (see the kernel) it wins at every length: a5 (SP = 128) 7.38 -> 7.04 ms, a5c32 (SP = 160, 186 registers,
+  // two waves per SIMD) 14.49 -> 13.84 ms.  EYEGAZE_ATTN_BWD1=0 forces the two-pass kernel.
+  if (single) {
     constexpr int lds1 = 2 * (3 * SP * 64 + 2 * SP * 4 + 2 * 2 * 32 * 32);
     static bool attr1 = false;
     if (!attr1) {
-      (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<T, (SP <= 128 ? SP : 96), 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+      (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<T, SP, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
       (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<T, 96, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
       attr1 = true;
     }
@@ -813,7 +821,7 @@ int launch_bwd(const void* qkv, const void* ctx, const void* dctx, const float* 
       hipLaunchKernelGGL((attn_bwd1_kernel<T, 96, 5, true>), dim3(nblk), dim3(256), lds1, s, (const T*)qkv, (const T*)ctx,
                          (const T*)dctx, lse, (T*)dqkv, NB, S, H, kv_shift, dc, st);
     else
-      hipLaunchKernelGGL((attn_bwd1_kernel<T, (SP <= 128 ? SP : 96), 0, false>), dim3(nblk), dim3(256), lds1, s, (const T*)qkv, (const T*)ctx,
+      hipLaunchKernelGGL((attn_bwd1_kernel<T, SP, 0, false>), dim3(nblk), dim3(256), lds1, s, (const T*)qkv, (const T*)ctx,
                          (const T*)dctx, lse, (T*)dqkv, NB, S, H, kv_shift, dc, st);
     return 0;
   }

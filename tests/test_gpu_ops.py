@@ -538,9 +538,9 @@ def test_reduce_table_wide_and_narrow_entries():
 
 @pytest.mark.parametrize("knob", ["0", "2"], ids=["two_pass_everywhere", "single_sweep_up_to_128"])
 def test_attention_backward_variants_not_selected_by_default(knob):
-    """The attention backward has two kernels (two-pass; single sweep, default for S <= 96).  The selection is read once per
-    process, so the non-default pairings -- two-pass at S <= 96, single sweep at 96 < S <= 128 -- are exercised by re-running
-    this file's attention tests in a child process with EYEGAZE_ATTN_BWD1 set."""
+    """The attention backward has two kernels (two-pass; single sweep, the default at every length since round 3).  The selection
+    is read once per process, so the non-default kernel (two-pass, knob 0; knob 2 is the default's old spelling) is exercised by
+    re-running this file's attention tests in a child process with EYEGAZE_ATTN_BWD1 set."""
     import os
     import subprocess
     import sys
