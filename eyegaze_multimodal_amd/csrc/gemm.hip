@@ -80,7 +80,10 @@ __device__ __forceinline__ float apply_act_t(float v) {
   return v;
 }
 
-template <typename T, int ACT>
+// NARROW: products with N <= 64 (the spectrogram / image convolutions' 64 output channels).  On the 128 x 128 tile the two waves of
+// columns 64 .. 127 multiply padding; here the tile is 256 rows x 64 columns -- wave (wm, wn) owns rows 128 wn + 64 wm .. + 63 of it --
+// so every MFMA is useful (conv-2 at C = 32: 930 + 593 us per step on the square tile).  Same k-ordered chains, same epilogue.
+template <typename T, int ACT, bool NARROW = false>
 __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmNT<T> p) {
   // 3 workgroups per CU: ONE 32 KiB LDS staging tile (the next K-tile waits in registers) and an epilogue that
   // passes the two 64-row halves of the tile through a 33 KiB fp32 LDS image one after the other.  The small-K
@@ -89,18 +92,22 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmNT<T> p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int bid = xcd_remap(blockIdx.x, p.nblocks);
-  const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
+  const int m0 = NARROW ? bid * 256 : (bid / p.tiles_n) * BM, n0 = NARROW ? 0 : (bid % p.tiles_n) * BN;
+  constexpr int NA = NARROW ? 8 : 4, NW = NARROW ? 2 : 4;       // 16-B pieces per thread of the A / W tile
+  constexpr int WOFF = NARROW ? 32768 : 16384;                   // the W tile behind the A tile
 
   // staging: each thread moves 4 x 16 B of the A tile and 4 x 16 B of the W tile per K-tile
   const int crow = tid >> 3, cch = tid & 7;
-  const char* ap[4];
-  const char* wp[4];
+  const char* ap[NA];
+  const char* wp[NW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = crow + 32 * i;
-    const int m = min(m0 + row, p.M - 1);
-    const int n = min(n0 + row, p.N - 1);
+  for (int i = 0; i < NA; ++i) {
+    const int m = min(m0 + crow + 32 * i, p.M - 1);
     ap[i] = (const char*)(p.A + row_off(p.a, m)) + cch * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int n = min(n0 + crow + 32 * i, p.N - 1);
     wp[i] = (const char*)(p.W + (long long)n * p.ldw) + cch * 16;
   }
   const int soff = crow * 128 + ((cch ^ (crow & 7)) << 4);
@@ -118,44 +125,42 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmNT<T> p) {
     const int sg = kt / p.seg_tiles;
     return (size_t)sg * (size_t)p.seg_stride_bytes + (size_t)(kt - sg * p.seg_tiles) * 128;
   };
-  u32x4 ra[4], rw[4];
+  u32x4 ra[NA], rw[NW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    ra[i] = *(const u32x4*)(ap[i]);
-    rw[i] = *(const u32x4*)(wp[i]);
-  }
+  for (int i = 0; i < NA; ++i) ra[i] = *(const u32x4*)(ap[i]);
+#pragma unroll
+  for (int i = 0; i < NW; ++i) rw[i] = *(const u32x4*)(wp[i]);
   // the epilogue's residual (or gate) rows are requested early so their latency hides under the K loop / under the
   // other half's epilogue: 4 x 16 B per thread and half (16-bit types only)
   constexpr bool kPre = sizeof(T) == 2;
   const T* const eop = p.residual ? p.residual : p.gate;
   const RowMap& emap = p.residual ? p.r : p.c;
-  const int en = n0 + (tid & 15) * 8;
+  const int en = n0 + (NARROW ? (tid & 7) : (tid & 15)) * 8;
   u32x4 pre[4];
   auto prefetch_epi = [&](int half) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = m0 + half * 64 + (tid >> 4) + 16 * i;
+      const int m = m0 + half * 64 + (NARROW ? (tid >> 3) + 32 * i : (tid >> 4) + 16 * i);
       pre[i] = (u32x4){0u, 0u, 0u, 0u};
-      if (kPre && eop && m < p.M && en < p.N) pre[i] = *(const u32x4*)(eop + row_off(emap, m) + en);
+      if (kPre && eop && (!NARROW || i < 2) && m < p.M && en < p.N) pre[i] = *(const u32x4*)(eop + row_off(emap, m) + en);
     }
   };
   prefetch_epi(0);
   for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *(u32x4*)(smem + soff + i * 4096) = ra[i];
-      *(u32x4*)(smem + 16384 + soff + i * 4096) = rw[i];
-    }
+    for (int i = 0; i < NA; ++i) *(u32x4*)(smem + soff + i * 4096) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) *(u32x4*)(smem + WOFF + soff + i * 4096) = rw[i];
     __syncthreads();
     if (kt + 1 < nk) {
       const size_t ka = koff(kt + 1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra[i] = *(const u32x4*)(ap[i] + ka);
-        rw[i] = *(const u32x4*)(wp[i] + (size_t)(kt + 1) * 128);
-      }
+      for (int i = 0; i < NA; ++i) ra[i] = *(const u32x4*)(ap[i] + ka);
+#pragma unroll
+      for (int i = 0; i < NW; ++i) rw[i] = *(const u32x4*)(wp[i] + (size_t)(kt + 1) * 128);
     }
-    mma_ktile<T>(smem, smem + 16384, wm, wn, lane, acc);
+    if (NARROW) mma_ktile<T>(smem, smem + WOFF, 2 * wn + wm, 0, lane, acc);      // row block 2 wn + wm, column block 0
+    else mma_ktile<T>(smem, smem + WOFF, wm, wn, lane, acc);
     __syncthreads();
   }
 
@@ -167,31 +172,31 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmNT<T> p) {
     seed_lo = p.st->seed_lo;
     seed_hi = p.st->seed_hi;
   }
-  const int ch = tid & 15;
+  const int ch = NARROW ? (tid & 7) : (tid & 15);
   const int n = n0 + ch * 8;
   float bv[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) bv[j] = 0.f;
   if (p.bias && n < p.N) load8(p.bias + n, bv);
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if (wm == half) {
+  for (int half = 0; half < (NARROW ? 4 : 2); ++half) {            // 64 rows of the tile per pass through the fp32 image
+    if ((NARROW ? 2 * wn + wm : wm) == half) {
       const int l15 = lane & 15, g = lane >> 4;
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
-          *(f32x4*)(ct + (mi * 16 + l15) * CT_PITCH + wn * 64 + ni * 16 + 4 * g) = acc[ni][mi];
+          *(f32x4*)(ct + (mi * 16 + l15) * CT_PITCH + (NARROW ? 0 : wn * 64) + ni * 16 + 4 * g) = acc[ni][mi];
     }
     __syncthreads();
     u32x4 cur[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) cur[i] = pre[i];
-    if (half == 0) prefetch_epi(1);
+    if (half + 1 < (NARROW ? 4 : 2)) prefetch_epi(half + 1);
     if (n < p.N) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 4) + 16 * i;
+      for (int i = 0; i < (NARROW ? 2 : 4); ++i) {
+        const int row = NARROW ? (tid >> 3) + 32 * i : (tid >> 4) + 16 * i;
         const int m = m0 + half * 64 + row;
         if (m >= p.M) continue;
         float v[8];
@@ -829,6 +834,17 @@ static int launch_gemm_nt(const eg_gemm_desc* d, hipStream_t s) {
   p.gate_scale = d->gate_scale == 0.f ? 1.0f : d->gate_scale;
   p.seg_tiles = d->a_seg_len > 0 ? d->a_seg_len / (128 / (int)sizeof(T)) : 0;
   p.seg_stride_bytes = (long long)d->a_seg_stride * (long long)sizeof(T);
+  static const bool use_narrow = [] { const char* e = getenv("EYEGAZE_NT_NARROW"); return !e || atoi(e) != 0; }();
+  if (use_narrow && d->N <= 64 && d->M >= 1024) {                     // one column tile of <= 64: 256 x 64 tiles (gemm_nt_kernel, NARROW)
+    p.tiles_n = 1;
+    p.nblocks = (d->M + 255) / 256;
+    constexpr int lds = 32768 + 8192;
+    if (d->act == EG_ACT_RELU) hipLaunchKernelGGL((gemm_nt_kernel<T, EG_ACT_RELU, true>), dim3(p.nblocks), dim3(256), lds, s, p);
+    else if (d->act == EG_ACT_GELU) hipLaunchKernelGGL((gemm_nt_kernel<T, EG_ACT_GELU, true>), dim3(p.nblocks), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<T, EG_ACT_NONE, true>), dim3(p.nblocks), dim3(256), lds, s, p);
+    EG_LAUNCH_CHECK("gemm_nt (narrow)");
+    return 0;
+  }
   if (d->act == EG_ACT_RELU) hipLaunchKernelGGL((gemm_nt_kernel<T, EG_ACT_RELU>), dim3(p.nblocks), dim3(256), NT_LDS_BYTES, s, p);
   else if (d->act == EG_ACT_GELU) hipLaunchKernelGGL((gemm_nt_kernel<T, EG_ACT_GELU>), dim3(p.nblocks), dim3(256), NT_LDS_BYTES, s, p);
   else hipLaunchKernelGGL((gemm_nt_kernel<T, EG_ACT_NONE>), dim3(p.nblocks), dim3(256), NT_LDS_BYTES, s, p);

@@ -56,7 +56,7 @@ def tol(dtype, k=1.0):
 
 
 @pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16, L.EG_F32])
-@pytest.mark.parametrize("shape", [(300, 136, 128), (520, 768, 256), (128, 128, 64), (33, 8, 1024)])
+@pytest.mark.parametrize("shape", [(300, 136, 128), (520, 768, 256), (128, 128, 64), (33, 8, 1024), (2500, 64, 384), (1100, 40, 128)])
 def test_gemm_nt_plain(dtype, shape):
     M, N, K = shape
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -109,6 +109,29 @@ def test_conv1d_as_grouped_gemm(dtype):
     wr = w.to(DT[dtype]).double()
     ref = torch.relu(torch.nn.functional.conv1d(xr, wr, b.double(), stride=s, padding=pad)).transpose(1, 2).reshape(NB * T1, dm)
     torch.testing.assert_close(out.cpu().double(), ref, **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16, L.EG_F32])
+def test_gemm_nt_narrow_tile_is_bit_identical_to_the_square_tile(dtype):
+    """N <= 64 with M >= 1024 runs on 256 x 64 tiles (gemm_nt_kernel NARROW: the spectrogram / image convolutions); below 1024 rows the
+    same product runs on the 128 x 128 tile.  Same k-ordered MFMA chains and epilogue: the first 1000 rows of a 3000-row launch must
+    equal a 1000-row launch bit for bit -- bias, ReLU, gate, both dropouts, second output and residual included."""
+    M, Ms, N, K = 3000, 1000, 64, 384
+    g = torch.Generator().manual_seed(31)
+    A = torch.randn(M, K, generator=g).to(DT[dtype]).to(DEV)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DT[dtype]).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).to(DT[dtype]).to(DEV)
+    gate = torch.randn(M, N, generator=g).to(DT[dtype]).to(DEV)
+    st = dev_state(seed=123)
+    outs = []
+    for m in (M, Ms):
+        pre = torch.zeros(m, N, device=DEV, dtype=DT[dtype])
+        out = gemm_nt(A[:m].contiguous(), W, m, N, K, dtype, bias=bias, residual=res[:m].contiguous(), gate=gate[:m].contiguous(),
+                      gate_scale=1.25, out_pre=pre, act=L.ACT_RELU, drop1=(0.1, 5), drop2=(0.2, 6), state=st)
+        outs.append((out, pre))
+    assert torch.equal(outs[0][0][:Ms], outs[1][0]) and torch.equal(outs[0][1][:Ms], outs[1][1])
+    assert torch.isfinite(outs[0][0].float()).all() and float(outs[0][0][Ms:].float().abs().sum()) > 0
 
 
 @pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16, L.EG_F32])
