@@ -38,6 +38,10 @@ int eg_fail(const char* fmt, ...);
     if (e__ != hipSuccess) return eg_fail("%s launch: %s", name, hipGetErrorString(e__)); \
   } while (0)
 
+// cross-file host helpers (not part of the C ABI)
+// gemm.hip: first stage of a long split reduction, IN PLACE (groups of consecutive slabs summed into each group's first slab)
+int eg_reduce_groups_inplace(float* partial, long long n, int splits, long long stride, int groups, int* group_out, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------------
 // bf16 <-> f32
 // ---------------------------------------------------------------------------------------------

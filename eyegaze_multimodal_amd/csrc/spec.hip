@@ -298,8 +298,6 @@ extern "C" int eg_pack_conv2d_weight(const float* w, void* dst, int N, int Cin, 
   return 0;
 }
 
-int eg_reduce_groups_inplace(float* partial, long long n, int splits, long long stride, int groups, int* group_out, hipStream_t s);   // gemm.hip
-
 extern "C" int eg_unpack_conv2d_wgrad(float* partial, float* dW, int splits, int N, int Cin, void* stream) {
   EG_CHECK(partial && dW && splits > 0 && N > 0 && Cin > 0, "eg_unpack_conv2d_wgrad: bad arguments");
   const long long slab = (long long)N * 12 * Cin;
