@@ -69,7 +69,7 @@ extern "C" int eg_debug_stamps(void* out) { return (int)hipMemcpyFromSymbol(out,
     k0 = s.index("void attn_bwd1_kernel(")
     head, body = s[:k0], s[k0:]
     body = rep(body, "  constexpr int NKT = SP / 16;\n", "  constexpr int NKT = SP / 16;\n  unsigned long long T0, T1, T2, T3, T4, T5;\n  STAMPV(T0);\n")
-    body = rep(body, "  if (qd < SP) {\n    float dsum = 0.f;", "  STAMPV(T5);\n  if (qd < SP) {\n    float dsum = 0.f;")
+    body = rep(body, "  rows_store<NCH>(doimg, rd, SP, first);\n", "  rows_store<NCH>(doimg, rd, SP, first);\n  STAMPV(T5);\n")
     body = rep(body, "  const uint32_t Sp2 = (uint32_t)((S + 1) & ~1);\n  __syncthreads();\n", "  const uint32_t Sp2 = (uint32_t)((S + 1) & ~1);\n  __syncthreads();\n  STAMPV(T1);\n")
     body = rep(body, "  // ---- dQ: role 0 finishes query tiles [0, NKT/2), role 1 the rest; each hands the other its partial of the other's tiles ----\n  __syncthreads();", "  STAMPV(T2);\n  __syncthreads();\n  STAMPV(T3);")
     e0 = body.index("// ------------------------------------------------------------------------------------------------\n// Exact-fp32 attention")
