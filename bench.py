@@ -285,7 +285,7 @@ def run_mm5(args, dev, world=1, rank=0, use_dist=False):
     tr.train_step(img1, img2, x1, x2, y)
     launches_per_step = len(probes)
     probes.clear()
-    n_probe_steps = min(8, max(2, args.steps // 10), args.steps)
+    n_probe_steps = min(4, max(1, args.steps // 20), args.steps)
     stream0 = torch.cuda.current_stream(dev)
     pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_probe_steps * launches_per_step)]
     for a_, b_ in pool:
@@ -540,7 +540,8 @@ def main():
     probes.clear()
     # the timed region's probe events are created (and recorded once, which is what materialises a hipEvent) HERE, outside it:
     # inside, a probed launch costs two hipEventRecord calls and the host stays ahead of the GPU
-    n_probe_steps = 0 if graphed is not None else min(8, max(2, args.steps // 10), args.steps)  # 8 of 100 steps, 2 of the driver's 20
+    # a probed step costs the host ~0.6 ms of hipEventRecord calls (the GPU idles meanwhile), so few steps are probed: 4 of 100, 1 of 20
+    n_probe_steps = 0 if graphed is not None else min(4, max(1, args.steps // 20), args.steps)
     stream0 = torch.cuda.current_stream(dev)
     pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             for _ in range(n_probe_steps * launches_per_step)]
