@@ -3,7 +3,8 @@
 //   P     = dropout(softmax(q k^T / sqrt(32)))  per head, lse stored
 //   ctx   = P v                      (stored: attention backward's delta term and the out-proj weight gradient read it)
 //   r1    = x + dropout(ctx Wo^T + bo)
-// As four launches (row-stream q|k|v GEMM, attention core, wide out-proj GEMM; LayerNorm stays its own launch) the layer moved
+// As three launches (row-stream q|k|v GEMM, attention core, wide out-proj GEMM; the LayerNorm that follows is a fourth unless ln_out
+// asks for it here) the layer moved
 // x twice, q|k|v twice and ctx twice through HBM: 204 MB per layer at the benchmark size (33 280 rows).  Here a workgroup owns
 // one WINDOW (S <= 80 token rows x 256 = 40 KB in LDS for the whole launch): x is read once and is also the residual, q|k|v and
 // ctx leave the chip once as results and are consumed on chip from LDS images: 102 MB.
@@ -21,7 +22,8 @@
 //   P3  out-proj partial sums: acc2[80 x 64 per wave] += ctx_chunk[80 x 64] Wo[:, chunk]^T (40 MFMAs, accumulators live in
 //       registers across the four chunks, k runs in ascending order exactly as in the stand-alone product);
 // final epilogue as eg_gemm_nt's: + bias, dropout, + residual (the LDS-resident x rows), 16-bit store.
-// Measured (MI355X, 512 windows of S = 65, p = 0.1): 54.5 us per launch against 25 + 27 + 20 us for the three launches; HBM traffic
+// Measured (MI355X, 512 windows of S = 65, p = 0.1): 54.5 us per launch against 25 + 27 + 20 us for the three launches (47.7 us as
+// the exact S = 65 instantiation, 53 us with norm1 in its tail); HBM traffic
 // by PMC 21.6 MB fetched + 86.3 MB written = 1.06 x the algorithmic 102 MB.  The launch is bound by the attention core's vector
 // work (exp + the dropout hash: ~1900 issue cycles per 16-query tile, 40 tiles per window over 4 waves, 3 : 2 between the two waves
 // of a head at S = 65), not by bandwidth; static s_setprio for the matrix phases measured no change (57.9 vs 58.2 us by HIP events).
