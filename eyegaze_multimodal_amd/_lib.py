@@ -61,6 +61,13 @@ class FfnDesc(C.Structure):
                 ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_out", C.c_void_p), ("ln_stats", C.c_void_p)]
 
 
+class LnBwdProjDesc(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("stats", C.c_void_p), ("gamma", C.c_void_p), ("W_frag", C.c_void_p),
+                ("dx", C.c_void_p), ("dx_drop", C.c_void_p), ("dC", C.c_void_p), ("partial", C.c_void_p), ("state", C.c_void_p),
+                ("M", C.c_int32), ("d_model", C.c_int32), ("dtype", C.c_int32), ("partial_capacity_blocks", C.c_int32),
+                ("drop1_p", C.c_float), ("drop2_p", C.c_float), ("drop1_site", C.c_uint32), ("drop2_site", C.c_uint32)]
+
+
 class AttnBlockDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("wqkv_frag", C.c_void_p), ("wo_frag", C.c_void_p), ("bqkv", C.c_void_p), ("bo", C.c_void_p),
                 ("qkv", C.c_void_p), ("ctx", C.c_void_p), ("lse", C.c_void_p), ("r1", C.c_void_p), ("state", C.c_void_p),
@@ -105,6 +112,8 @@ SIGNATURES = {
     "eg_gemm_nt": [C.POINTER(GemmDesc), _P],
     "eg_gemm_nt_route": [C.POINTER(GemmDesc)],
     "eg_ffn_chain": [C.POINTER(FfnDesc), _P],
+    "eg_ln_bwd_proj": [C.POINTER(LnBwdProjDesc), _P],
+    "eg_ln_bwd_proj_blocks": [_I],
     "eg_attn_block_fwd": [C.POINTER(AttnBlockDesc), _P],
     "eg_attn_block_ok": [_I, _I, _I, _I],
     "eg_gemm_tn": [C.POINTER(GemmTNDesc), _P],

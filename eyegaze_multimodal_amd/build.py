@@ -11,7 +11,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libeyegaze_hip.so"
-SOURCES = ["prep.hip", "gemm.hip", "rsgemm.hip", "widegemm.hip", "ffn.hip", "attnblock.hip", "norm.hip", "attention.hip", "heads.hip", "optim.hip", "signal.hip", "spec.hip", "aux.hip"]
+SOURCES = ["prep.hip", "gemm.hip", "rsgemm.hip", "widegemm.hip", "ffn.hip", "lnproj.hip", "attnblock.hip", "norm.hip", "attention.hip", "heads.hip", "optim.hip", "signal.hip", "spec.hip", "aux.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 

@@ -301,6 +301,31 @@ __device__ __forceinline__ void eg_epilogue_layernorm256(const float (&vv)[5][16
   }
 }
 
+// LayerNorm backward of one row of 256, 8 elements per lane over a HALF-wave (32 lanes): shared by layernorm_bwd256_kernel and
+// ln_bwd_proj_kernel so that both produce the same bits -- every product / sum is an explicit round-to-nearest intrinsic (left to the
+// compiler, `dv * g - c1` became an fma in one kernel and a rounded product minus c1 in the other: one bf16 step apart now and then).
+__device__ __forceinline__ float eg_half_sum32(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ void eg_ln_bwd_row8(const float (&xv)[8], const float (&dv)[8], const float (&g)[8], float mean, float rstd,
+                                               float (&dg)[8], float (&db)[8], float (&o)[8]) {
+  float xh[8], dxh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    xh[e] = __fmul_rn(__fsub_rn(xv[e], mean), rstd);
+    dg[e] = __fmaf_rn(dv[e], xh[e], dg[e]);
+    db[e] = __fadd_rn(db[e], dv[e]);
+    dxh[e] = __fmul_rn(dv[e], g[e]);
+    s1 = __fadd_rn(s1, dxh[e]);
+    s2 = __fmaf_rn(dxh[e], xh[e], s2);
+  }
+  const float c1 = __fmul_rn(eg_half_sum32(s1), 1.0f / 256.f), c2 = __fmul_rn(eg_half_sum32(s2), 1.0f / 256.f);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = __fmul_rn(rstd, __fmaf_rn(-xh[e], c2, __fsub_rn(dxh[e], c1)));
+}
+
 // XCD-aware bijective remap of a linear block id (8 XCDs, round-robin dispatch): blocks that are
 // neighbours after the remap share an XCD (and its L2).  Speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {

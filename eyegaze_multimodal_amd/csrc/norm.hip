@@ -217,21 +217,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd256_kernel(const T* __restri
     float xv[8], dv[8];
     load8((const T*)&cur.x[0], xv);
     load8((const T*)&cur.d[0], dv);
-    float xh[8], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      xh[e] = (xv[e] - mean) * rstd;
-      dg[e] += dv[e] * xh[e];
-      db[e] += dv[e];
-      const float dxh = dv[e] * g[e];
-      s1 += dxh;
-      s2 += dxh * xh[e];
-    }
-    const float c1 = half_sum(s1) * (1.0f / 256.f), c2 = half_sum(s2) * (1.0f / 256.f);
+    float o[8];
+    eg_ln_bwd_row8(xv, dv, g, mean, rstd, dg, db, o);
     if (ok) {
-      float o[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = rstd * (dv[e] * g[e] - c1 - xh[e] * c2);
       store8(dx + (size_t)row * 256 + l * 8, o);
       if (dx_drop) {
         if (drop) {

@@ -180,6 +180,10 @@ class Engine:
         # norm1, eg_ffn_chain forward -> norm2) instead of two launches that re-read them; the statistics are summed in another order
         # than eg_layernorm_fwd's, so the step agrees with EYEGAZE_LN_FUSE=0 to rounding, not bit for bit
         self.ln_fuse = os.environ.get("EYEGAZE_LN_FUSE", "1") != "0"
+        # norm1's backward and out_proj's backward-data product as one launch over 80-row tiles (eg_ln_bwd_proj): bit-identical to the
+        # two launches (the gain / bias partials are grouped by tile instead of by LayerNorm block: equal to fp32 rounding)
+        self.ln_proj = (dtype != EG_F32 and cfg.d_model == 256 and os.environ.get("EYEGAZE_LN_PROJ", "1") != "0")
+        self.ln_proj_blocks = L.lib().eg_ln_bwd_proj_blocks(self.M) if self.ln_proj else 0
         self._alloc()
         self.packed_version = -1
         self._recording = False
@@ -205,6 +209,8 @@ class Engine:
             w[f"o{l}"] = self._t(d, d)
             w[f"oT{l}"] = self._t(d, d)
             w[f"bqkv{l}"] = self._t(3 * d, dtype=f32)
+            if self.ln_proj and l != "x":             # out_proj^T in MFMA-fragment order (eg_pack_table mode 6) for eg_ln_bwd_proj
+                w[f"oTf{l}"] = self._t(d * d)
             if self.attn_block and l != "x":          # eg_attn_block_fwd's fragment-ordered q|k|v and out-proj weights
                 w[f"wqkvb{l}"] = self._t(3 * d * d)
                 w[f"wob{l}"] = self._t(d * d)
@@ -656,7 +662,7 @@ class Engine:
             for k, (i, n) in enumerate(lns):   # deferred LayerNorm gain / bias partials ride in the same reduce launch
                 r = rt[len(sel) + k]
                 r.partial, r.out = ptr(g["lnpart_all"]) + 4 * i * self.ln_nblk_cap * 2 * d, fp.g_ptr(n + ".weight")
-                r.n, r.stride, r.splits, r.blk0 = 2 * d, 2 * d, self.LN_BLOCKS, rblk
+                r.n, r.stride, r.splits, r.blk0 = 2 * d, 2 * d, (self.ln_proj_blocks if (self.ln_proj and n.endswith(".ln1")) else self.LN_BLOCKS), rblk
                 rblk += _reduce_blocks(2 * d, r.splits)
             return dict(tp=dev(tp), rt=dev(rt), n=len(sel), nr=len(sel) + len(lns), blocks=blk, rblocks=rblk, layers=list(layers),
                         splits=nsplit)
@@ -681,6 +687,26 @@ class Engine:
     def ln_fwd(self, x, gname, y, stats):
         call("eg_layernorm_fwd", ptr(x), self.fp.p_ptr(gname + ".weight"), self.fp.p_ptr(gname + ".bias"), ptr(y),
              ptr(stats), self.M, self.cfg.d_model, self.dtype, self.stream)
+
+    def ln_bwd_proj(self, dy, x, stats, gname, wfrag, dx, dx_drop, dC, d1=(0.0, 0), slot=None):
+        """eg_ln_bwd_proj: LayerNorm backward + the backward-data product dC = dx_drop W^T in one launch (csrc/lnproj.hip)"""
+        d = self.cfg.d_model
+        nblk = self.ln_proj_blocks
+        lp = ptr(self.g["lnpart"]) if slot is None else ptr(self.g["lnpart_all"]) + 4 * slot * self.ln_nblk_cap * 2 * d
+        cap = self.LN_PARTIAL_BLOCKS if slot is None else self.ln_nblk_cap
+        dsc = L.LnBwdProjDesc()
+        dsc.dy, dsc.x, dsc.stats, dsc.gamma, dsc.W_frag = ptr(dy), ptr(x), ptr(stats), self.fp.p_ptr(gname + ".weight"), ptr(wfrag)
+        dsc.dx, dsc.dx_drop, dsc.dC, dsc.partial, dsc.state = ptr(dx), ptr(dx_drop), ptr(dC), lp, self.st_ptr
+        dsc.M, dsc.d_model, dsc.dtype, dsc.partial_capacity_blocks = self.M, d, self.dtype, cap
+        dsc.drop1_p, dsc.drop1_site = d1
+        call("eg_ln_bwd_proj", C.byref(dsc), self.stream)
+        if slot is not None:
+            return
+        if self.fp.offsets[gname + ".bias"] == self.fp.offsets[gname + ".weight"] + d:
+            call("eg_reduce_partials", lp, self.fp.g_ptr(gname + ".weight"), 2 * d, nblk, 2 * d, 0, self.stream)
+        else:
+            call("eg_reduce_partials", lp, self.fp.g_ptr(gname + ".weight"), d, nblk, 2 * d, 0, self.stream)
+            call("eg_reduce_partials", lp + 4 * d, self.fp.g_ptr(gname + ".bias"), d, nblk, 2 * d, 0, self.stream)
 
     def ln_bwd(self, dy, x, stats, gname, dx, dx_drop=None, d1=(0.0, 0), d2=(0.0, 0), slot=None):
         """slot: index into the deferred gain/bias partial buffer (reduced by the grouped reduce at the end of backward)"""
@@ -756,6 +782,8 @@ class Engine:
                 self.p_copy(fp.p_ptr(f"{pre}{n}.bias"), ptr(w[f"bqkv{l}"]) + 4 * i * d, d)
             self.p_cast(fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"o{l}"]), d * d)
             self.p_transpose(fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"oT{l}"]), d, d, d)
+            if self.ln_proj and l != "x":
+                self.p_frag(fp.p_ptr(f"{pre}out_proj.weight"), ptr(w[f"oTf{l}"]), d, d, 6)
             if self.attn_block and l != "x":
                 for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
                     self.p_frag(fp.p_ptr(f"{pre}{n}.weight"), ptr(w[f"wqkvb{l}"]), d, d, 7, part=i)
@@ -935,12 +963,13 @@ class Engine:
         pcs = os.environ.get("EYEGAZE_WGRAD_PIECES", "")
         pieced = grouped and len(self._wg_plan["pieces"]) == 2 and pcs != "0" and (on_segment is not None or pcs == "1")
 
-        def attn_block_bwd(pre, l, x_in, dr, drm, kv_shift, site_attn, dx_out, dqkv, defer):
+        def attn_block_bwd(pre, l, x_in, dr, drm, kv_shift, site_attn, dx_out, dqkv, defer, dctx_done=False):
             """dr: grad of the pre-LN sum (residual path), drm: same, masked by the branch dropout."""
             names = [pre + n for n in ("q_proj", "k_proj", "v_proj")]
             if not defer:
                 self.wgrad(ptr(drm), ptr(a[f"ctx{l}"]), 0, M, d, d, linear=[pre + "out_proj"])
-            self.gemm(ptr(drm), ptr(w[f"oT{l}"]), ptr(g["dctx"]), M, d, d)
+            if not dctx_done:       # (eg_ln_bwd_proj has written dctx together with dr / drm)
+                self.gemm(ptr(drm), ptr(w[f"oT{l}"]), ptr(g["dctx"]), M, d, d)
             call("eg_attention_bwd", ptr(a[f"qkv{l}"]), ptr(a[f"ctx{l}"]), ptr(g["dctx"]), ptr(a[f"lse{l}"]), ptr(dqkv),
                  NB, S, H, kv_shift, self.dtype, p, site_attn, self.st_ptr, st)
             if not defer:
@@ -996,12 +1025,17 @@ class Engine:
                 self.wgrad(ptr(dh), ptr(a[f"y1_{l}"]), 0, M, F, d, linear=[pre + "ffn.linear1"])
             if not self.fuse_ffn:
                 self.gemm(ptr(dh), ptr(w[f"w1T{l}"]), ptr(g["dy1"]), M, d, F, residual=ptr(dr))
-            if has_drop:
-                self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", g["dr"], dYo, d1=(p, sites["drop1"]), slot=s1)
+            if self.ln_proj:        # norm1 backward + out_proj backward-data in one launch
+                self.ln_bwd_proj(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", w[f"oTf{l}"], g["dr"], dYo, g["dctx"],
+                                 d1=(p, sites["drop1"]) if has_drop else (0.0, 0), slot=s1)
+                dr = g["dr"]
             else:
-                self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", dYo, None, slot=s1)
-            dr = g["dr"] if has_drop else dYo
-            attn_block_bwd(pre + "mha.", l, a[f"x{l}"], dr, dYo, 0, sites["attn"], other, dqkv, grouped)
+                if has_drop:
+                    self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", g["dr"], dYo, d1=(p, sites["drop1"]), slot=s1)
+                else:
+                    self.ln_bwd(g["dy1"], a[f"r1_{l}"], a[f"st1_{l}"], pre + "ln1", dYo, None, slot=s1)
+                dr = g["dr"] if has_drop else dYo
+            attn_block_bwd(pre + "mha.", l, a[f"x{l}"], dr, dYo, 0, sites["attn"], other, dqkv, grouped, dctx_done=self.ln_proj)
             dz, other = other, dz
             if not grouped:
                 seg(f"layer{l}")

@@ -193,6 +193,31 @@ int eg_ffn_chain(const eg_ffn_desc* d, void* stream);
 int64_t eg_ffn_gate_bits_bytes(int M, int F);
 
 /* ---------------------------------------------------------------------------------------------
+ * eg_ln_bwd_proj — LayerNorm backward (d_model = 256) and the backward-data product that consumes it, one launch over 80-row tiles:
+ *   dx = LayerNorm backward of dy (what eg_layernorm_bwd writes, bit for bit), dx_drop = dropout1(dropout2(dx)) (ditto),
+ *   dC = dx_drop * W^T with W[256, 256] pre-packed in fragment order (eg_pack_table mode 5 / 6; bit-identical to eg_gemm_nt),
+ *   partial[block][512] = the block's gain | bias gradient sums (eg_ln_bwd_proj_blocks(M) rows; reduce with eg_reduce_partials).
+ *   Replaces autograd's backward of `norm1` (A:293) + of `out_proj` (A:213) of an encoder layer.  16-bit dtypes.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct eg_ln_bwd_proj_desc {
+  const void* dy;       /* [M, 256] gradient of the LayerNorm output */
+  const void* x;        /* [M, 256] the LayerNorm input */
+  const float* stats;   /* [M, 2] mean, rstd of the forward */
+  const float* gamma;   /* [256] */
+  const void* W_frag;   /* 256 x 256 elements in fragment order */
+  void* dx;             /* out [M, 256] */
+  void* dx_drop;        /* out [M, 256] */
+  void* dC;             /* out [M, 256] */
+  float* partial;       /* out [blocks, 512] */
+  const eg_step_state* state;
+  int32_t M, d_model, dtype, partial_capacity_blocks;
+  float drop1_p, drop2_p;
+  uint32_t drop1_site, drop2_site;
+} eg_ln_bwd_proj_desc;
+int eg_ln_bwd_proj(const eg_ln_bwd_proj_desc* d, void* stream);
+int eg_ln_bwd_proj_blocks(int M);   /* rows of `partial` a launch over M rows writes */
+
+/* ---------------------------------------------------------------------------------------------
  * eg_attn_block_fwd — the attention half of a post-LN encoder layer in ONE launch, a workgroup per WINDOW (S <= 80 rows):
  *   q|k|v = x Wqkv^T + b (A:203-205) -> softmax(q k^T / sqrt(32)), attention dropout, P v per head (A:206-212) ->
  *   r1 = x + dropout(ctx Wo^T + bo) (A:213, A:292-293's residual; the LayerNorm stays eg_layernorm_fwd).
