@@ -17,28 +17,64 @@ struct BandTable {
 typedef float2 cf;
 __device__ __forceinline__ cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
-// in-LDS radix-2 Stockham FFT of length N (power of two), all threads of the block cooperate.
-// x: input/output buffer, y: scratch, tw: table exp(-2 pi i k / N), k < N/2.  inverse => conjugated twiddles, no scaling.
-// Returns the buffer that holds the result (natural order).
+// in-LDS radix-4 Stockham autosort FFT of length N (power of two; one closing radix-2 stage when log2 N is odd), all threads of the
+// block cooperate.  x: input/output buffer, y: scratch, tw: table exp(-2 pi i k / N), k < N/2.  inverse => conjugated twiddles, no
+// scaling.  Returns the buffer that holds the result (natural order).
+// A radix-4 stage is two radix-2 stages at one pass through LDS and one barrier: per output point 2.1 instead of 7 index / address
+// instructions and half the LDS traffic (the radix-2 form spent 19 vector instructions per butterfly, 10 of them arithmetic, and
+// was half of eg_ibs_analytic).  s, the stride, is a power of two: p = j >> log2 s.
 __device__ cf* fft_stockham(cf* x, cf* y, const cf* tw, int N, bool inverse) {
-  int n = N, s = 1;
-  while (n > 1) {
-    const int m = n >> 1;
+  int n = N, ls = 0;
+  const float isg = inverse ? 1.f : -1.f;                        // forward: multiply by -i, inverse: by +i
+  while (n >= 4) {
+    const int m = n >> 2;
     const int tstep = N / n;
-    for (int j = threadIdx.x; j < (N >> 1); j += blockDim.x) {
-      const int p = j / s, q = j - p * s;
-      cf w = tw[p * tstep];
-      if (inverse) w.y = -w.y;
-      const cf a = x[q + s * p], b = x[q + s * (p + m)];
-      y[q + s * (2 * p)] = make_float2(a.x + b.x, a.y + b.y);
-      y[q + s * (2 * p + 1)] = cmul(make_float2(a.x - b.x, a.y - b.y), w);
+    const int s = 1 << ls;
+    for (int j = threadIdx.x; j < (N >> 2); j += blockDim.x) {
+      const int p = j >> ls, q = j & (s - 1);
+      cf w1 = tw[p * tstep], w2 = tw[2 * p * tstep];
+      if (inverse) { w1.y = -w1.y; w2.y = -w2.y; }
+      const cf w3 = cmul(w1, w2);
+      const cf* in = x + q + s * p;
+      const cf a0 = in[0], a1 = in[s * m], a2 = in[2 * s * m], a3 = in[3 * s * m];
+      const cf t0 = make_float2(a0.x + a2.x, a0.y + a2.y), t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+      const cf t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
+      const cf d3 = make_float2(a1.x - a3.x, a1.y - a3.y);
+      const cf t3 = make_float2(-isg * d3.y, isg * d3.x);        // (a1 - a3) * (+-i)
+      cf* out = y + q + s * 4 * p;
+      out[0] = make_float2(t0.x + t2.x, t0.y + t2.y);
+      out[s] = cmul(make_float2(t1.x + t3.x, t1.y + t3.y), w1);
+      out[2 * s] = cmul(make_float2(t0.x - t2.x, t0.y - t2.y), w2);
+      out[3 * s] = cmul(make_float2(t1.x - t3.x, t1.y - t3.y), w3);
     }
     __syncthreads();
     cf* t = x; x = y; y = t;
     n = m;
-    s <<= 1;
+    ls += 2;
+  }
+  if (n == 2) {                                                  // closing radix-2 stage: s = N/2, p = 0, unit twiddle
+    const int s = N >> 1;
+    for (int q = threadIdx.x; q < s; q += blockDim.x) {
+      const cf a = x[q], b = x[q + s];
+      y[q] = make_float2(a.x + b.x, a.y + b.y);
+      y[q + s] = make_float2(a.x - b.x, a.y - b.y);
+    }
+    __syncthreads();
+    cf* t = x; x = y; y = t;
   }
   return x;
+}
+
+// three block sums behind one pair of barriers; per value the order of additions is block_sum's
+__device__ __forceinline__ void block_sum3(float& a, float& b, float& c, float* red) {
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = a; red[8 + (threadIdx.x >> 6)] = b; red[16 + (threadIdx.x >> 6)] = c;
+  }
+  __syncthreads();
+  a = b = c = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { a += red[i]; b += red[8 + i]; c += red[16 + i]; }
 }
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
@@ -62,7 +98,7 @@ __global__ __launch_bounds__(256) void ibs_analytic_kernel(const float* __restri
   cf* bufA = bufX + T;         // [T] work
   cf* bufB = bufA + T;         // [T] work
   cf* tw = bufB + T;           // [T/2]
-  __shared__ float red[8];
+  __shared__ float red[24];
   const int sig = blockIdx.x;
   for (int k = threadIdx.x; k < (T >> 1); k += blockDim.x) {
     float sn, cs;
@@ -95,7 +131,8 @@ __global__ __launch_bounds__(256) void ibs_analytic_kernel(const float* __restri
       const float p = re * re;
       s1 += re; s2 += p; s4 += p * p;
     }
-    const float S1 = block_sum(s1, red), S2 = block_sum(s2, red), S4 = block_sum(s4, red);
+    block_sum3(s1, s2, s4, red);
+    const float S1 = s1, S2 = s2, S4 = s4;
     if (threadIdx.x == 0) {
       const float n = (float)T;
       const float mx = S1 / n, mp = S2 / n;
@@ -111,38 +148,66 @@ __global__ __launch_bounds__(256) void ibs_analytic_kernel(const float* __restri
 
 __device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
 
-// grid (B, nbands, tiles_i * tiles_j): 8x8 channel tile of player 1 x player 2.
+// sin and cos of an atan2f result (|x| <= pi): quadrant by Cody-Waite (pi/2 in two pieces), then the two degree-7 / degree-8
+// minimax polynomials of the Cephes single-precision sinf / cosf on [-pi/4, pi/4].  Absolute error <= 9.3e-8 over [-pi, pi]
+// (checked on 4 M points against float64; a correctly rounded result is off by up to 6.2e-8), at 25 vector instructions for the pair
+// instead of the ~90 of sincosf, whose argument reduction has to cover every float.
+__device__ __forceinline__ void sincos_atan2(float x, float& s, float& c) {
+  const float kf = rintf(x * 0.636619772f);
+  float r = fmaf(kf, -1.5707963705f, x);
+  r = fmaf(kf, 4.3711388e-8f, r);
+  const float z = r * r;
+  float sp = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+  sp = fmaf(sp * z, r, r);
+  float cp = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+  cp = fmaf(cp * z, z, fmaf(-0.5f, z, 1.0f));
+  const int n = (int)kf;
+  const bool sw = n & 1;
+  const float ss = sw ? cp : sp, cc = sw ? sp : cp;
+  s = (n & 2) ? -ss : ss;
+  c = ((n + 1) & 2) ? -cc : cc;
+}
+
+// 1-D grid of B * nbands * tiles_i * tiles_j workgroups: an 8x8 channel tile of player 1 x player 2 each.  Consecutive workgroup ids
+// go to consecutive XCDs, so the id is turned round first (XCD x owns one contiguous eighth of the logical ids): the tiles_i * tiles_j
+// tiles of one (window pair, band) -- which read each channel row tiles_j (tiles_i) times -- then run next to each other on ONE
+// XCD and find the rows in its L2 (round 3's first form, grid (B, nbands, tiles), had them 1536 workgroups apart: 3.44 GB fetched
+// for 0.81 GB of rows at C = 32).
 // out conn [B, nbands, 7, C, C] in the reference's feature order [PLV, PLI, wPLI, Coherence, Power_Corr, Phase_Diff, Time_Corr]
-// One time step of a channel is staged into LDS ONCE per tile with everything a pair needs from it -- the band signal a, its phase,
-// cos / sin of the phase and the two z-scores (power, signal) -- so the 64 pairs of the tile cost a handful of multiply-adds per
-// time step: cos(p1 - p2) = c1 c2 + s1 s2, sin(p1 - p2) = s1 c2 - c1 s2 instead of one sincosf per PAIR and time step (the round-2
-// form: 100 M precise sincosf calls per step at C = 8, 1.6 G at the reference's default C = 32, where the launch was 38 % of the
-// whole training step).  A lane owns one time step and walks its wave's 16 pairs (2 channels of player 1 x 8 of player 2) with the
-// ten channel values in registers; per lane the time steps and so the summation order are those of the round-2 kernel, so every
-// feature but PLV (the identity instead of sincosf: 1e-7) is bit-identical to it.
-constexpr int IBS_TC = 256;          // time steps per LDS tile: 2 players x 4 arrays x 8 channels x 256 x 4 B = 64 KB -> two workgroups per CU;
-                                     // one's staging (memory latency) runs beside the other's pair loop (512 steps = 128 KB, one per CU: 4.75 ms at C = 32)
-__global__ __launch_bounds__(256) void ibs_pairs_kernel(const float* __restrict__ xb, const float* __restrict__ phase,
+// One time step of a channel is staged into LDS ONCE per tile as the quad (band signal a, phase p, cos p, sin p), so the 64 pairs
+// of the tile cost a handful of multiply-adds per time step: cos(p1 - p2) = c1 c2 + s1 s2, sin(p1 - p2) = s1 c2 - c1 s2 instead of
+// one sincosf per PAIR and time step.  A lane owns one time step and walks its wave's 16 pairs (2 channels of player 1 x 8 of
+// player 2); the two player-1 channels ride in the two halves of packed fp32 operations (v_pk_fma/mul/add_f32: 2 flops per lane and
+// issue slot), which with sign(d) as clamp(d * 2^96 * 2^96, -1, 1) and |d| = sign(d) * d brings a pair and time step from 21.8
+// vector instructions to 10 (the sum of w over time is closed-form from the channel statistics and not accumulated).  Per lane the time steps and so the summation order are those of the earlier kernels.
+constexpr int IBS_RED_FLOATS = 32 * 68;   // per wave: 32 values x (64 lanes + 4 pad)
+constexpr int IBS_TC = 256;          // time steps per LDS tile: 16 channels x 256 x 16 B = 64 KB -> two workgroups per CU;
+                                     // one's staging (memory latency) runs beside the other's pair loop
+__global__ __launch_bounds__(256, 2) void ibs_pairs_kernel(const float* __restrict__ xb, const float* __restrict__ phase,
                                                         const float* __restrict__ stats, const cf* __restrict__ spec,
                                                         float* __restrict__ conn, int B, int C, int T, float fs, int nbin,
                                                         BandTable bt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Tc = min(T, IBS_TC);
-  // [player][array: a, phase, cos, sin][channel 8][Tc]
-  float* const lds = (float*)smem;
-  const int b = blockIdx.x, band = blockIdx.y;
+  f32x4* const lds = (f32x4*)smem;                               // [player * 8 + channel][Tc] quads (a, p, cos p, sin p)
   const int tj = (C + 7) / 8;
-  const int i0 = (blockIdx.z / tj) * 8, j0 = (blockIdx.z % tj) * 8;
+  const int tiles = tj * tj;
+  int wg = blockIdx.x;
+  if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);
+  const int tile = wg % tiles, bb = wg / tiles;
+  const int band = bb % bt.nbands, b = bb / bt.nbands;
+  const int i0 = (tile / tj) * 8, j0 = (tile % tj) * 8;
   const int nsig = 2 * B * C;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float acc[16][8];
+  f32x2 acc[8][8];                                               // [player-2 channel v][feature]; halves = player-1 channels 2 wave, 2 wave + 1
 #pragma unroll
-  for (int a = 0; a < 16; ++a)
+  for (int v = 0; v < 8; ++v)
 #pragma unroll
-    for (int f = 0; f < 8; ++f) acc[a][f] = 0.f;
+    for (int f = 0; f < 8; ++f) acc[v][f] = (f32x2){0.f, 0.f};
   // z-score constants of this wave's channels: player 1 channels 2 wave, 2 wave + 1; player 2 channels 0..7 of the tile
-  float m1[2], r1[2], mp1[2], rp1[2], m2[8], r2[8], mp2[8], rp2[8];
+  f32x2 m1, r1, mp1, rp1;
+  float m2[8], r2[8], mp2[8], rp2[8];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const float* s1 = stats + ((size_t)band * nsig + (size_t)b * C + min(i0 + 2 * wave + u, C - 1)) * 4;
@@ -153,75 +218,64 @@ __global__ __launch_bounds__(256) void ibs_pairs_kernel(const float* __restrict_
     const float* s2 = stats + ((size_t)band * nsig + (size_t)(b + B) * C + min(j0 + v, C - 1)) * 4;
     m2[v] = s2[0]; r2[v] = s2[1]; mp2[v] = s2[2]; rp2[v] = s2[3];
   }
+  // staging: a thread takes one time step of a channel per element -- 4-B loads, coalesced across the wave, and ONE 16-B LDS write at
+  // a 16-B lane stride (free of bank conflicts; four time steps per thread would write at a 64-B stride, four ways conflicted).
+  // The (signal, phase) values of chunk c + 1 are requested BEFORE the pair loop of chunk c and converted after it, so their memory
+  // latency runs under the loop (T is a power of two >= 64, so every chunk has Tc steps: 16 Tc / 256 <= 16 elements per thread).
+  const int lt = __builtin_ctz(Tc);
+  const int nel = 16 * Tc;
+  const float* const xbB = xb + (size_t)band * nsig * T;         // this band's rows; element offsets below fit 32 bits (nsig * T < 2^31)
+  const float* const phB = phase + (size_t)band * nsig * T;
+  float av[16], pv[16];
+  auto request = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = min((int)threadIdx.x + 256 * u, nel - 1);
+      const int pc = e >> lt, c = pc & 7;                         // pc = player * 8 + channel of the tile
+      const uint32_t row = (pc & 8) ? (uint32_t)((b + B) * C + min(j0 + c, C - 1)) : (uint32_t)(b * C + min(i0 + c, C - 1));
+      const uint32_t o = row * (uint32_t)T + (uint32_t)(t0 + (e & (Tc - 1)));
+      av[u] = xbB[o];
+      pv[u] = phB[o];
+    }
+  };
+  request(0);
   for (int t0 = 0; t0 < T; t0 += Tc) {
-    const int tn = min(Tc, T - t0);
+    const int tn = Tc;
     __syncthreads();
-    // staging: 16-B loads, FOUR (signal, phase) pairs requested before the first is consumed -- with one workgroup per CU the
-    // one-load-per-trip form of round 2 exposed a full memory latency per element and was most of the launch
-    const int tq = tn >> 2;                                       // float4 groups per channel (T is a power of two >= 64)
-    const int nvec = 16 * tq;
-    for (int v0 = threadIdx.x; v0 < nvec; v0 += 4 * 256) {
-      f32x4 av[4], pv[4];
-      int off[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int v = v0 + 256 * u;
-        off[u] = -1;
-        if (v < nvec) {
-          const int pc = v / tq, t = (v - pc * tq) << 2;          // pc = player * 8 + channel of the tile
-          const int pl = pc >> 3, c = pc & 7;
-          const int ch = pl ? min(j0 + c, C - 1) : min(i0 + c, C - 1);
-          const size_t sidx = ((size_t)band * nsig + (size_t)(pl ? b + B : b) * C + ch) * T + t0 + t;
-          av[u] = *(const f32x4*)(xb + sidx);
-          pv[u] = *(const f32x4*)(phase + sidx);
-          off[u] = pl * 4 * 8 * Tc + c * Tc + t;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (off[u] >= 0) {
-          f32x4 cs, sn;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float s_, c_;
-            sincosf(pv[u][e], &s_, &c_);
-            cs[e] = c_; sn[e] = s_;
-          }
-          float* base = lds + off[u];
-          *(f32x4*)base = av[u]; *(f32x4*)(base + 8 * Tc) = pv[u]; *(f32x4*)(base + 16 * Tc) = cs; *(f32x4*)(base + 24 * Tc) = sn;
-        }
+    for (int u = 0; u < 16; ++u) {
+      const int e = threadIdx.x + 256 * u;
+      if (e < nel) {
+        float s_, c_;
+        sincos_atan2(pv[u], s_, c_);
+        lds[e] = (f32x4){av[u], pv[u], c_, s_};                  // (e >> lt) * Tc + (e & (Tc - 1)) = e
       }
     }
     __syncthreads();
-    const float* const P1 = lds + (2 * wave) * Tc;              // player 1, this wave's first channel
-    const float* const P2 = lds + 4 * 8 * Tc;                   // player 2, channel 0
+    if (t0 + Tc < T) request(t0 + Tc);
+    const f32x4* const P1 = lds + (2 * wave) * Tc;               // player 1, this wave's first channel
+    const f32x4* const P2 = lds + 8 * Tc;                        // player 2, channel 0
     for (int t = lane; t < tn; t += 64) {
-      float a1[2], p1[2], c1[2], s1[2], zq1[2], za1[2], q1[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        a1[u] = P1[u * Tc + t]; p1[u] = P1[(8 + u) * Tc + t]; c1[u] = P1[(16 + u) * Tc + t]; s1[u] = P1[(24 + u) * Tc + t];
-        q1[u] = a1[u] * a1[u];
-        zq1[u] = (q1[u] - mp1[u]) * rp1[u];
-        za1[u] = (a1[u] - m1[u]) * r1[u];
-      }
+      const f32x4 x0 = P1[t], x1 = P1[Tc + t];
+      const f32x2 a1 = {x0[0], x1[0]}, p1 = {x0[1], x1[1]}, c1 = {x0[2], x1[2]}, s1 = {x0[3], x1[3]};
+      const f32x2 q1 = a1 * a1;
+      const f32x2 zq1 = (q1 - mp1) * rp1, za1 = (a1 - m1) * r1;
 #pragma unroll
       for (int v = 0; v < 8; ++v) {
-        const float a2 = P2[v * Tc + t], p2 = P2[(8 + v) * Tc + t], c2 = P2[(16 + v) * Tc + t], s2 = P2[(24 + v) * Tc + t];
+        const f32x4 y = P2[v * Tc + t];
+        const float a2 = y[0], p2 = y[1], c2 = y[2], s2 = y[3];
         const float q2 = a2 * a2;
         const float zq2 = (q2 - mp2[v]) * rp2[v], za2 = (a2 - m2[v]) * r2[v];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int a = u * 8 + v;                               // pair (2 wave + u, v) = round-2's pair index wave * 16 + a
-          const float d = p1[u] - p2;
-          const float cs = c1[u] * c2 + s1[u] * s2;
-          const float sn = s1[u] * c2 - c1[u] * s2;
-          const float sg = sgn(d);
-          const float w = (q1[u] + q2) * 0.5f;
-          acc[a][0] += cs; acc[a][1] += sn; acc[a][2] += sg; acc[a][3] += sg * w; acc[a][4] += w;
-          acc[a][5] += fabsf(d);
-          acc[a][6] += zq1[u] * zq2;
-          acc[a][7] += za1[u] * za2;
-        }
+        const f32x2 d = p1 - p2;
+        const f32x2 big = (d * 0x1p96f) * 0x1p96f;                // 0 stays 0; anything else, subnormal differences included, passes 1
+        const f32x2 sg = {__builtin_amdgcn_fmed3f(big[0], -1.f, 1.f), __builtin_amdgcn_fmed3f(big[1], -1.f, 1.f)};
+        const f32x2 w = (q1 + q2) * 0.5f;
+        acc[v][0] += c1 * c2; acc[v][0] += s1 * s2;              // cos(p1 - p2), one fma per product
+        acc[v][1] += s1 * c2; acc[v][1] -= c1 * s2;              // sin(p1 - p2)
+        acc[v][2] += sg; acc[v][3] += sg * w;
+        acc[v][5] += sg * d;                                     // |d|
+        acc[v][6] += zq1 * zq2;
+        acc[v][7] += za1 * za2;
       }
     }
   }
@@ -229,8 +283,7 @@ __global__ __launch_bounds__(256) void ibs_pairs_kernel(const float* __restrict_
   const float df = fs / (float)T;
   // ---- coherence: mean over the T/2+1 rFFT bins of |X1 X2*|^2 / (|X1|^2 |X2|^2 + 1e-8); only in-band bins are non-zero.
   //      The in-band spectra of the tile's 16 channels are staged into LDS once (the time-domain tile is finished), and a pair walks
-  //      bins [klo, khi] only.  (Round 2 read both spectra from global memory per pair and bin, behind a band test on all 513 bins:
-  //      16 pairs x 9 trips of exposed load latency per wave, at one wave per SIMD -- most of the launch's 8.8 ms at C = 32.) ----
+  //      bins [klo, khi] only. ----
   int klo = max(0, (int)ceilf(bt.lo[band] / df)), khi = min(nbin - 1, (int)floorf(bt.hi[band] / df));
   // the band test of the reference is on f = k * df evaluated in fp32 (D:551): settle the two edges with that very predicate
   while (klo > 0 && (float)(klo - 1) * df >= bt.lo[band]) --klo;
@@ -239,42 +292,68 @@ __global__ __launch_bounds__(256) void ibs_pairs_kernel(const float* __restrict_
   while (khi >= 0 && (float)khi * df > bt.hi[band]) --khi;
   const int nin = max(0, khi - klo + 1);                 // <= 179 bins (0.5 .. 45 Hz at df = 0.25 Hz) x 16 channels x 8 B = 23 KB
   __syncthreads();
-  cf* const sp = (cf*)smem;                              // [player * 8 + channel][nin]
+  // LDS of the tail: spectra [player * 8 + channel][nin] | per wave 32 x 68 floats of transposed partial sums | per wave 128 totals
+  cf* const sp = (cf*)smem;
+  float* const red = (float*)(smem + (size_t)16 * nbin * sizeof(cf)) + wave * IBS_RED_FLOATS;
+  float* const tot = (float*)(smem + (size_t)16 * nbin * sizeof(cf)) + 4 * IBS_RED_FLOATS + wave * 128;
   for (int idx = threadIdx.x; idx < 16 * nin; idx += blockDim.x) {
     const int pc = idx / nin, k = idx - pc * nin;
     const int pl = pc >> 3, c = pc & 7;
     const int ch = pl ? min(j0 + c, C - 1) : min(i0 + c, C - 1);
     sp[idx] = spec[((size_t)(pl ? b + B : b) * C + ch) * nbin + klo + k];
   }
-  __syncthreads();
+  // the wave's 16 pairs x 8 sums over its 64 lanes: every lane writes its 32 values of a pass as a column, lane l < 32 then adds up
+  // row l (16 reads of 16 B).  128 values cost 128 4-B writes and 64 16-B reads per wave -- the butterfly (six dependent
+  // ds_bpermute per value, 768 per wave, two or three in flight) was a third of the launch.
 #pragma unroll
-  for (int a = 0; a < 16; ++a) {
-    const int pr = wave * 16 + a, ii = pr >> 3, jj = pr & 7;
-    float v[8];
+  for (int pass = 0; pass < 4; ++pass) {
 #pragma unroll
-    for (int f = 0; f < 8; ++f) v[f] = wave_sum(acc[a][f]);
-    float coh = 0.f;
+    for (int i = 0; i < 32; ++i) {
+      const int a = 4 * pass + (i >> 3), f = i & 7;             // pair a = u * 8 + v of the wave, feature f
+      red[i * 68 + lane] = (f == 4) ? 0.f : acc[a & 7][f][a >> 3];   // slot 4 (sum of w) is closed-form, below
+    }
+    __syncthreads();
+    if (lane < 32) {
+      const f32x4* row = (const f32x4*)(red + lane * 68);
+      f32x4 sacc = row[0];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) sacc += row[q];
+      tot[32 * pass + lane] = (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
+    }
+    __syncthreads();
+  }
+  // coherence: lane = (pair a, quarter of the bins); the quarters meet in two shuffles
+  const int a = lane & 15, sub = lane >> 4;
+  const int pr = wave * 16 + a, ii = pr >> 3, jj = pr & 7;
+  float coh = 0.f;
+  {
     const cf* f1 = sp + ii * nin;
     const cf* f2 = sp + (8 + jj) * nin;
-    for (int k = lane; k < nin; k += 64) {
+    for (int k = sub; k < nin; k += 4) {
       const cf u = f1[k], w = f2[k];
       const cf xy = cmul(u, make_float2(w.x, -w.y));
       const float num = xy.x * xy.x + xy.y * xy.y;
       const float pxx = u.x * u.x + u.y * u.y, pyy = w.x * w.x + w.y * w.y;
       coh += num / (pxx * pyy + 1e-8f);
     }
-    coh = wave_sum(coh) / (float)(T / 2 + 1);
-    if (lane == 0 && i0 + ii < C && j0 + jj < C) {
-      float* o = conn + (((size_t)b * bt.nbands + band) * 7) * C * C + (size_t)(i0 + ii) * C + (j0 + jj);
-      const size_t fs_ = (size_t)C * C;
-      o[0 * fs_] = sqrtf(v[0] * v[0] + v[1] * v[1]) * invT;
-      o[1 * fs_] = fabsf(v[2] * invT);
-      o[2 * fs_] = fabsf(v[3] / (v[4] + 1e-8f));
-      o[3 * fs_] = coh;
-      o[4 * fs_] = v[6] * invT;
-      o[5 * fs_] = v[5] * invT;
-      o[6 * fs_] = v[7] * invT;
-    }
+    coh += __shfl_xor(coh, 16, 64);
+    coh += __shfl_xor(coh, 32, 64);
+    coh /= (float)(T / 2 + 1);
+  }
+  if (sub == 0 && i0 + ii < C && j0 + jj < C) {
+    const f32x4 v0 = *(const f32x4*)(tot + 8 * a), v1 = *(const f32x4*)(tot + 8 * a + 4);
+    float* o = conn + (((size_t)b * bt.nbands + band) * 7) * C * C + (size_t)(i0 + ii) * C + (j0 + jj);
+    const size_t fs_ = (size_t)C * C;
+    o[0 * fs_] = sqrtf(v0[0] * v0[0] + v0[1] * v0[1]) * invT;
+    o[1 * fs_] = fabsf(v0[2] * invT);
+    // sum over time of w = (q1 + q2) / 2 needs no pair loop: the per-channel mean of q = a^2 is in the statistics
+    const float sw = 0.5f * (float)T * (stats[((size_t)band * nsig + (size_t)b * C + (i0 + ii)) * 4 + 2] +
+                                        stats[((size_t)band * nsig + (size_t)(b + B) * C + (j0 + jj)) * 4 + 2]);
+    o[2 * fs_] = fabsf(v0[3] / (sw + 1e-8f));
+    o[3 * fs_] = coh;
+    o[4 * fs_] = v1[2] * invT;
+    o[5 * fs_] = v1[1] * invT;
+    o[6 * fs_] = v1[3] * invT;
   }
 }
 
@@ -522,17 +601,22 @@ extern "C" int eg_ibs_pairs(const float* xb, const float* phase, const float* st
                             void* stream) {
   EG_CHECK(xb && phase && stats && spec && conn, "eg_ibs_pairs: null pointer");
   EG_CHECK(B > 0 && C > 0 && T > 0, "eg_ibs_pairs: bad shape");
+  EG_CHECK(is_pow2(T) && T >= 64 && T <= 2048, "eg_ibs_pairs: T=%d must be a power of two in [64, 2048]", T);
+  EG_CHECK((int64_t)2 * B * C * T < ((int64_t)1 << 31), "eg_ibs_pairs: 2 B C T = %lld elements per band exceed 32-bit offsets", (long long)2 * B * C * T);
   BandTable bt;
   EG_CHECK(fill_bands(bt, band_lo, band_hi, nbands) == 0, "eg_ibs_pairs: nbands=%d", nbands);
   const int Tc = T < IBS_TC ? T : IBS_TC;
-  const int lds = 2 * 4 * 8 * Tc * 4;            // two players x (a, phase, cos, sin) x 8 channels x Tc
+  const int lds_time = 16 * Tc * 16;             // 16 channels x Tc quads (a, phase, cos, sin)
+  const int lds_tail = 16 * nbin * 8 + (4 * IBS_RED_FLOATS + 4 * 128) * 4;   // spectra + transposed sums + totals
+  const int lds = lds_time > lds_tail ? lds_time : lds_tail;
+  EG_CHECK(nbin > 0 && lds <= 160 * 1024, "eg_ibs_pairs: nbin=%d needs %d bytes of LDS", nbin, lds);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)ibs_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 8 * IBS_TC * 4);
+    (void)hipFuncSetAttribute((const void*)ibs_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   const int tiles = ((C + 7) / 8) * ((C + 7) / 8);
-  hipLaunchKernelGGL(ibs_pairs_kernel, dim3(B, nbands, tiles), dim3(256), lds, (hipStream_t)stream, xb, phase, stats,
+  hipLaunchKernelGGL(ibs_pairs_kernel, dim3(B * nbands * tiles), dim3(256), lds, (hipStream_t)stream, xb, phase, stats,
                      (const cf*)spec, conn, B, C, T, fs, nbin, bt);
   EG_LAUNCH_CHECK("ibs_pairs");
   return 0;

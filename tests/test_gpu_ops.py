@@ -379,6 +379,42 @@ def test_stft_and_ibs_connectivity_match_oracle():
     assert d[:, flip].max() < 2e-3
 
 
+@pytest.mark.parametrize("B,Cc,T", [(2, 12, 512), (1, 32, 256), (2, 5, 128), (1, 16, 2048)])
+def test_ibs_connectivity_shapes(B, Cc, T):
+    """eg_ibs_analytic + eg_ibs_pairs against the CPU oracle away from the bench shape: channel counts that are not a multiple of the
+    8 x 8 tile (padded lanes must not reach the output), several tiles per window pair (the XCD-ordered 1-D grid), an odd log2 T
+    (the closing radix-2 stage of the FFT) and windows shorter / longer than one 256-step LDS chunk."""
+    import ctypes as CT
+    from oracle import dual_eeg_oracle as O
+    fs = 256.0
+    g = torch.Generator().manual_seed(100 + Cc + T)
+    base = torch.randn(B, Cc, T, generator=g)
+    t_ = torch.arange(T) / fs
+    x1 = base + torch.sin(2 * math.pi * 10 * t_) + 0.5 * torch.sin(2 * math.pi * 22 * t_ + 1.0)
+    x2 = 0.6 * base.roll(5, dims=2) + 0.4 * torch.randn(B, Cc, T, generator=g) + torch.sin(2 * math.pi * 10 * t_ + 0.7)
+    bands = O.ROBUST_BANDS
+    lo = (CT.c_float * 6)(*[b[0] for b in bands])
+    hi = (CT.c_float * 6)(*[b[1] for b in bands])
+    nsig, nbin = 2 * B * Cc, min(T // 2 + 1, int(45.0 * T / fs) + 1)
+    xcat = torch.cat([x1, x2], 0).contiguous().to(DEV)
+    xb, ph = torch.zeros(6, nsig, T, device=DEV), torch.zeros(6, nsig, T, device=DEV)
+    stats, spec = torch.zeros(6, nsig, 4, device=DEV), torch.zeros(nsig, nbin, 2, device=DEV)
+    conn = torch.full((B, 6, 7, Cc, Cc), float("nan"), device=DEV)
+    call("eg_ibs_analytic", ptr(xcat), ptr(xb), ptr(ph), ptr(stats), ptr(spec), nsig, T, fs, nbin, CT.addressof(lo), CT.addressof(hi), 6, 0)
+    call("eg_ibs_pairs", ptr(xb), ptr(ph), ptr(stats), ptr(spec), ptr(conn), B, Cc, T, fs, nbin, CT.addressof(lo), CT.addressof(hi), 6, 0)
+    torch.cuda.synchronize()
+    ref = O.ibs_connectivity(x1, x2, O.ModelCfg(in_channels=Cc)).numpy()
+    got = conn.cpu().numpy()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(xb[0, :B * Cc].cpu().numpy().reshape(B, Cc, T), O.bandpass(x1, fs, 0.5, 45).numpy(), atol=2e-5)
+    for f in range(7):
+        d = np.abs(got[:, :, f] - ref[:, :, f])
+        if f in (1, 2):   # sign()-based: one flipped sample of T moves PLI by 2/T
+            assert (d > 1e-4).mean() < 5e-3 and d.max() < 6.5 / T, (f, d.max())
+        else:
+            assert d.max() < 1e-4, (f, d.max())
+
+
 def test_heads_and_ce():
     B, S, D, ncls, off = 8, 20, 64, 3, 5
     dtype = L.EG_F32
