@@ -294,18 +294,20 @@ def run_mm5(args, dev, world=1, rank=0, use_dist=False):
     for e in engines:
         e.probe_all, e.probe_pool = None, pool
     torch.cuda.synchronize()
+    gc.collect()    # BEFORE the warm-up: a collection between warm-up and timed region leaves the GPU idle for tens of ms
+    gc.disable()
     for _ in range(args.warmup):
         tr.train_step(img1, img2, x1, x2, y)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    gc.collect()
-    gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         for e in engines:
-            e.probe_all = probes if i < n_probe_steps else None
+            e.probe_all = probes if i >= args.steps - n_probe_steps else None
         out = tr.train_step(img1, img2, x1, x2, y)
+    for e in engines:
+        e.probe_all = None
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -550,20 +552,23 @@ def main():
         b_.record(stream0)
     eng.probe_pool = pool
     torch.cuda.synchronize()
+    # no cyclic-GC pause inside the timed region: a step allocates a few hundred short-lived ctypes descriptors and event
+    # tuples, and a generation-2 collection over the process' tensors costs tens of milliseconds -- invisible in 100 steps,
+    # a doubling of ms/step in a 20-step run.  Collected BEFORE the warm-up steps, so that the GPU does not sit idle between
+    # the warm-up and the timed region.
+    import gc
+    gc.collect()
+    gc.disable()
     for i in range(args.warmup):
         step(i)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    # no cyclic-GC pause inside the timed region: a step allocates a few hundred short-lived ctypes descriptors and event
-    # tuples, and a generation-2 collection over the process' tensors costs tens of milliseconds -- invisible in 100 steps,
-    # a doubling of ms/step in a 20-step run
-    import gc
-    gc.collect()
-    gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i, probe=(i < n_probe_steps))  # events on the launch stream, read after the region
+        # the probed steps are the LAST of the region: the host is then several steps ahead of the GPU, so the ~0.6 ms of
+        # hipEventRecord calls of a probed step hide behind queued work (as the first step after the synchronize they idled the GPU)
+        step(args.warmup + i, probe=(i >= args.steps - n_probe_steps))  # events on the launch stream, read after the region
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -585,7 +590,7 @@ def main():
         value = world * B * args.steps / elapsed
         # eg_gemm_nt (every forward product -- strided convs, q/k/v/out, heads -- and every backward-data product) routes a launch
         # to one of its kernels (eg_gemm_nt_route); eg_ffn_chain is the feed-forward pair.  HIP events bracket EVERY such launch
-        # of the timed region's first steps on the launch stream; launches are grouped by the kernel they ran, and `roofline`
+        # of the timed region's last steps on the launch stream; launches are grouped by the kernel they ran, and `roofline`
         # describes the group with the most GPU time = the step's dominant kernel (rocprofv3 --kernel-trace --stats of this command
         # under profiles/ agrees).  Per launch (averaged over that kernel's launches of a step): algorithmic FLOPs = 2*M*N*K,
         # algorithmic bytes = each distinct operand/output element once (Engine._gemm_bytes).  With d_model = 256 the products
