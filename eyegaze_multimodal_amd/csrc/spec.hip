@@ -215,6 +215,132 @@ __global__ __launch_bounds__(256) void unpack_conv2d_wgrad_kernel(const float* _
   dW[(((size_t)n * Cin + c) * 3 + ky) * 3 + kx] = s;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// conv-2 weight gradient as a FLAT correlation (16-bit operands, N = 64 outputs, Cin = 32).
+// Activations p1 and output gradients d2 live in the same padded pixel rows [image row][Wp + 4 pixels][channels]; with q the flat
+// padded pixel index, the 3 x 3 window of output pixel q is p1[q + ky * rowpx + kx] and its gradient is d2[q + rowpx + 1].  The pads
+// of d2 are zero (eg_spec_avgpool_bwd writes interiors only), so the sum may run over EVERY q:
+//     dW[n][ky][kx][c] = sum_q d2[q + rowpx + 1][n] * p1[q + ky * rowpx + kx][c]
+// -- nine GEMMs over q whose X operand is the same LDS image read at nine row offsets.  The im2col form (eg_gemm_tn with a sliding
+// row map) fetched every p1 pixel twelve times and every d2 row three times through L2 and ran half of its 128-column MFMA tile on
+// padding: 0.93 ms at C = 32; here each operand byte reaches LDS once.
+// Workgroup = one split of q; 256-row stages (Y 32 KB + X 20 KB incl. a 64-row halo) in ONE buffer, the next stage waits in
+// registers.  Wave w multiplies all four 16-wide n-tiles by channel tile (w & 1) of taps 0..4 (w < 2) or 5..8: 20 or 16 MFMA per
+// 32-row step against 9 KB of fragment reads.  Fragments by ds_read_b64_tr_b16 (the recipe of tn_mma); 32-B slots swizzled so that
+// the eight rows a half-wave touches never share a slot, at any tap offset.
+// Output: partial[split][n][(ky * 4 + kx) * 32 + c], the slab layout eg_unpack_conv2d_wgrad reduces (pad taps kx = 3 unwritten).
+// ------------------------------------------------------------------------------------------------
+constexpr int CW_QC = 256, CW_HALO = 64;    // halo >= 2 rowpx + 2: rowpx <= 31
+constexpr int CW_YB = CW_QC * 128, CW_XB = (CW_QC + CW_HALO) * 64;
+
+__device__ __forceinline__ int cw_yoff(int row, int slot) { return row * 128 + ((slot ^ (((row >> 1) & 1) | (((row >> 3) & 1) << 1))) << 5); }
+__device__ __forceinline__ int cw_xoff(int row, int slot) { return row * 64 + ((slot ^ ((row >> 3) & 1)) << 5); }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv2d_wgrad_flat_kernel(const T* __restrict__ d2, const T* __restrict__ p1,
+                                                                   float* __restrict__ partial, long long Q, long long p1_rows,
+                                                                   int rowpx, long long rows_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename H16<T>::frag frag;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  char* const bufY = smem;
+  char* const bufX = smem + CW_YB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cj = wave & 1, tap0 = (wave >> 1) * 5, ntap = 5 - (wave >> 1);
+  const long long qbeg = (long long)blockIdx.x * rows_per_split;
+  const long long qend = qbeg + rows_per_split < Q ? qbeg + rows_per_split : Q;
+  const T* const yb = d2 + (size_t)(rowpx + 1) * 64;             // gradient of output pixel q
+
+  f32x4 acc[5][4];
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int toff[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int tt = min(tap0 + t, 8);
+    toff[t] = (tt / 3) * rowpx + (tt % 3);
+  }
+
+  // staging map: Y chunk c = tid + 256 i (i < 8): row c >> 3, 16-B piece c & 7;  X chunk c = tid + 256 i (i < 5): row c >> 2, piece c & 3
+  u32x4 ry[8], rx[5];
+  auto load_stage = [&](long long q0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 256 * i, row = c >> 3, pc = c & 7;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      ry[i] = z;
+      if (q0 + row < qend) ry[i] = *(const u32x4*)(yb + (size_t)(q0 + row) * 64 + pc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int c = tid + 256 * i, row = c >> 2, pc = c & 3;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      rx[i] = z;
+      if (row < CW_QC + CW_HALO && q0 + row < p1_rows) rx[i] = *(const u32x4*)(p1 + (size_t)(q0 + row) * 32 + pc * 8);
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 256 * i, row = c >> 3, pc = c & 7;
+      *(u32x4*)(bufY + cw_yoff(row, pc >> 1) + (pc & 1) * 16) = ry[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int c = tid + 256 * i, row = c >> 2, pc = c & 3;
+      if (row < CW_QC + CW_HALO) *(u32x4*)(bufX + cw_xoff(row, pc >> 1) + (pc & 1) * 16) = rx[i];
+    }
+  };
+
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  if (qbeg < qend) load_stage(qbeg);
+  for (long long q0 = qbeg; q0 < qend; q0 += CW_QC) {
+    store_stage();
+    __syncthreads();
+    if (q0 + CW_QC < qend) load_stage(q0 + CW_QC);
+#pragma unroll 2
+    for (int ks = 0; ks < CW_QC / 32; ++ks) {
+      const int r0 = 32 * ks + 8 * g + qq, r1 = r0 + 4;
+      frag yf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bufY + cw_yoff(r0, i) + 8 * pp));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bufY + cw_yoff(r1, i) + 8 * pp));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        yf[i] = __builtin_bit_cast(frag, v);
+      }
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        if (t < ntap) {
+          const int a0 = r0 + toff[t], a1 = r1 + toff[t];
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bufX + cw_xoff(a0, cj) + 8 * pp));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bufX + cw_xoff(a1, cj) + 8 * pp));
+          const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const frag xf = __builtin_bit_cast(frag, v);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[t][i] = H16<T>::mfma(xf, yf[i], acc[t][i]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // D[i = channel][j = n]: lane holds 4 consecutive channels (4 g + r) of column n = lane & 15
+  float* out = partial + (size_t)blockIdx.x * (64 * 384);
+  const int l15 = lane & 15;
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    if (t < ntap) {
+      const int tt = tap0 + t, kcol = ((tt / 3) * 4 + (tt % 3)) * 32 + cj * 16 + 4 * g;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *(f32x4*)(out + (size_t)(i * 16 + l15) * 384 + kcol) = acc[t][i];
+    }
+  }
+}
+
 }  // namespace
 
 #define SPEC_DISPATCH(dtype, BF, F16, F32, who)   \
@@ -313,4 +439,43 @@ extern "C" int eg_unpack_conv2d_wgrad(float* partial, float* dW, int splits, int
   hipLaunchKernelGGL(unpack_conv2d_wgrad_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, partial, dW, splits, stride, N, Cin);
   EG_LAUNCH_CHECK("unpack_conv2d_wgrad");
   return 0;
+}
+
+extern "C" int eg_conv2d_wgrad_flat(const void* d2, const void* p1, float* partial, long long Q, long long p1_rows, int rowpx,
+                                    int splits, int dtype, void* stream) {
+  EG_CHECK(d2 && p1 && partial && Q > 0 && rowpx >= 4 && 2 * rowpx + 2 <= CW_HALO && splits > 0, "eg_conv2d_wgrad_flat: bad arguments");
+  EG_CHECK(p1_rows >= Q + 2 * rowpx + 2, "eg_conv2d_wgrad_flat: p1 holds %lld pixel rows, the windows of %lld pixels reach %lld", p1_rows, Q,
+           Q + 2 * rowpx + 2);
+  EG_CHECK(dtype == EG_BF16 || dtype == EG_F16, "eg_conv2d_wgrad_flat: 16-bit operands only (dtype %d); fp32 goes through eg_gemm_tn", dtype);
+  // rows per split: a multiple of the 256-row stage; every split must own at least one row
+  long long rps = ((Q + splits - 1) / splits + CW_QC - 1) / CW_QC * CW_QC;
+  EG_CHECK((long long)(splits - 1) * rps < Q, "eg_conv2d_wgrad_flat: %d splits of %lld rows overrun Q = %lld (use eg_conv2d_wgrad_flat_splits)",
+           splits, rps, Q);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv2d_wgrad_flat_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_YB + CW_XB);
+    (void)hipFuncSetAttribute((const void*)conv2d_wgrad_flat_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, CW_YB + CW_XB);
+    attr = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EG_BF16)
+    hipLaunchKernelGGL(conv2d_wgrad_flat_kernel<bf16_t>, dim3(splits), dim3(256), CW_YB + CW_XB, s, (const bf16_t*)d2, (const bf16_t*)p1,
+                       partial, Q, p1_rows, rowpx, rps);
+  else
+    hipLaunchKernelGGL(conv2d_wgrad_flat_kernel<f16_t>, dim3(splits), dim3(256), CW_YB + CW_XB, s, (const f16_t*)d2, (const f16_t*)p1,
+                       partial, Q, p1_rows, rowpx, rps);
+  EG_LAUNCH_CHECK("conv2d_wgrad_flat");
+  return 0;
+}
+
+// the largest split count <= want whose 256-row-aligned splits all own rows
+extern "C" int eg_conv2d_wgrad_flat_splits(long long Q, int want) {
+  if (Q <= 0 || want <= 0) return 0;
+  int splits = want;
+  while (splits > 1) {
+    const long long rps = ((Q + splits - 1) / splits + CW_QC - 1) / CW_QC * CW_QC;
+    if ((long long)(splits - 1) * rps < Q) break;
+    --splits;
+  }
+  return splits;
 }

@@ -3,6 +3,7 @@ synchrony (IBS) tokens, matrix form (D:473-911) or scalar form (D:178-470).  Cal
 module hooks; every op is a C-ABI kernel (signal.hip, spec.hip, gemm.hip).  D = dual_eeg_transformer.py."""
 from __future__ import annotations
 
+import os
 import ctypes as C
 
 import torch
@@ -11,6 +12,7 @@ from . import _lib as L
 from ._lib import EG_F32, call, ptr, rowmap
 from .engine import SITE_IBSGEN, SITE_IBSTOK, SITE_SPEC, Engine, _align
 
+CONV2_WGRAD_FLAT = os.environ.get("EYEGAZE_CONV2_WGRAD_FLAT", "1") != "0"   # 0: the conv-2 weight gradient as an im2col eg_gemm_tn
 ROBUST_BANDS = [(0.5, 45.0), (0.5, 4.0), (4.0, 8.0), (8.0, 13.0), (13.0, 30.0), (30.0, 45.0)]  # D:500-507
 SCALAR_BANDS = [(4.0, 8.0), (8.0, 13.0), (13.0, 30.0), (30.0, 45.0)]                           # D:201-206
 
@@ -280,9 +282,20 @@ def spec_cnn_backward(eng, pre, dy_ptr, dmap, sc01):
     eng.gemm(ptr(g["sp_dhp0"]), ptr(w["spp0T"]), ptr(g["sp_dpooled"]), nimg, 1024, 2 * d)
     call("eg_spec_avgpool_bwd", ptr(a["sp_out2"]), ptr(g["sp_dpooled"]), ptr(g["sp_d2"]), nimg, Hp, Wp, dt, st)
     row32, row64 = (Wp + 4) * 32, (Wp + 4) * 64
-    eng.wgrad(ptr(g["sp_d2"]) + (row64 + 64) * es, ptr(a["sp_p1"]), fp.g_ptr(pre + "spec_conv.3.weight"), rows, 64, 384,
-              y=rowmap(64, row64, Wp), x=rowmap(32, row32, Wp), x_tile_stride=row32, conv2d=(64, 32),
-              out_b=fp.g_ptr(pre + "spec_conv.3.bias"))
+    if dt != L.EG_F32 and CONV2_WGRAD_FLAT and 2 * (Wp + 4) + 2 <= 64:   # (the kernel's LDS halo holds two image rows + 2 pixels)
+        # 16-bit operands: the flat correlation (csrc/spec.hip) reads every activation / gradient byte once; the im2col product below
+        # fetched p1 twelve times and d2 three times through L2 (0.93 ms of the C = 32 step)
+        Q = nimg * (Hp + 2) * (Wp + 4)
+        splits = L.lib().eg_conv2d_wgrad_flat_splits(Q, min(2 * eng.cus, eng.tn_cap // (64 * 384)))
+        call("eg_conv2d_wgrad_flat", ptr(g["sp_d2"]), ptr(a["sp_p1"]), ptr(g["partial"]), Q, Q + 4 * (Wp + 4), Wp + 4, splits, dt, st)
+        call("eg_unpack_conv2d_wgrad", ptr(g["partial"]), fp.g_ptr(pre + "spec_conv.3.weight"), splits, 64, 32, st)
+        nblk = min(512, (rows + 63) // 64)
+        call("eg_colsum", ptr(g["sp_d2"]) + (row64 + 64) * es, rowmap(64, row64, Wp), rows, 64, ptr(g["cspart"]), nblk, dt, st)
+        call("eg_reduce_partials", ptr(g["cspart"]), fp.g_ptr(pre + "spec_conv.3.bias"), 64, nblk, 64, 0, st)
+    else:
+        eng.wgrad(ptr(g["sp_d2"]) + (row64 + 64) * es, ptr(a["sp_p1"]), fp.g_ptr(pre + "spec_conv.3.weight"), rows, 64, 384,
+                  y=rowmap(64, row64, Wp), x=rowmap(32, row32, Wp), x_tile_stride=row32, conv2d=(64, 32),
+                  out_b=fp.g_ptr(pre + "spec_conv.3.bias"))
     eng.gemm(ptr(g["sp_d2"]), ptr(w["spc2T"]), ptr(g["sp_dp1"]), rows, 32, 768, a=rowmap(64, row64, Wp), seg=(256, row64))
     call("eg_spec_conv1_bwd", ptr(a["spimg"]), fp.p_ptr(pre + "spec_conv.0.weight"), fp.p_ptr(pre + "spec_conv.0.bias"),
          ptr(g["sp_dp1"]), ptr(g["sp_part"]), nimg, F, nfr, dt, st)

@@ -468,6 +468,14 @@ int eg_spec_avgpool_fwd(const void* out2, void* pooled, int nimg, int Hp, int Wp
 int eg_spec_avgpool_bwd(const void* out2, const void* dpooled, void* d2, int nimg, int Hp, int Wp, int dtype, void* stream);
 int eg_pack_conv2d_weight(const float* w, void* dst, int N, int Cin, int transposed, int dtype, void* stream);
 int eg_unpack_conv2d_wgrad(float* partial /* scratch: reduced in place when splits > 64 */, float* dW, int splits, int N, int Cin, void* stream);
+/* Weight gradient of Conv2d(32,64,3,p1) (autograd's grad_weight of D:74) as a flat correlation over the padded pixel index q
+ * (16-bit operands): partial[split][n][(ky*4+kx)*32 + c] = sum over the split's q of d2[q + rowpx + 1][n] * p1[q + ky*rowpx + kx][c],
+ * Q = nimg*(Hp+2)*rowpx pixels, rowpx = Wp + 4.  The pads of d2 must be zero (eg_spec_avgpool_bwd writes interiors only); p1 must hold
+ * p1_rows >= Q + 2*rowpx + 2 readable pixel rows.  The slabs are the ones eg_unpack_conv2d_wgrad reduces (pad taps kx = 3 are not
+ * written).  eg_conv2d_wgrad_flat_splits: the largest split count <= want whose 256-pixel-aligned splits all own pixels. */
+int eg_conv2d_wgrad_flat(const void* d2, const void* p1, float* partial, long long Q, long long p1_rows, int rowpx, int splits,
+                         int dtype, void* stream);
+int eg_conv2d_wgrad_flat_splits(long long Q, int want);
 
 #ifdef __cplusplus
 }

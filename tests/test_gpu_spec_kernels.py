@@ -2,7 +2,8 @@
 them only at B = 4, where e.g. the two-stage reduction of eg_unpack_conv2d_wgrad never runs):
   * eg_unpack_conv2d_wgrad: dW[n][c][ky][kx] = sum over splits of partial[s][n][(ky * 4 + kx) * Cin + c], short and long reductions;
   * eg_spec_avgpool_fwd / _bwd (D:118-123): 4 x 4 adaptive average pooling of the post-ReLU conv-2 image and its gradient;
-  * eg_colsum at N = 64 (the convolutions' bias gradients) and at the encoder's widths."""
+  * eg_colsum at N = 64 (the convolutions' bias gradients) and at the encoder's widths;
+  * eg_conv2d_wgrad_flat: the conv-2 weight gradient as a flat correlation, against autograd's grad_weight on the same 16-bit operands."""
 import pytest
 import torch
 
@@ -61,3 +62,33 @@ def test_colsum(shape, dtype):
     call("eg_colsum", ptr(Y), rowmap(N), M, N, ptr(part), nblk, dtype, 0)
     torch.cuda.synchronize()
     torch.testing.assert_close(part.double().sum(0), Y.double().sum(0), rtol=1e-4, atol=2e-3 * (M ** 0.5) / 30)
+
+
+@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16])
+@pytest.mark.parametrize("shape,want", [((6, 8, 8), 3), ((40, 32, 8), 64), ((3, 8, 4), 1), ((9, 16, 24), 7), ((2, 4, 12), 512)])
+def test_conv2d_wgrad_flat(shape, want, dtype):
+    """dW of Conv2d(32, 64, 3, padding=1) from the padded pixel rows the forward / pooling kernels keep (p1 [nimg, Hp+2, Wp+4, 32],
+    d2 [nimg, Hp+2, Wp+4, 64], image at rows 1..Hp, pixels 1..Wp), against torch's grad_weight in float64 on the same rounded
+    operands; splits that end inside a stage, a last split shorter than the others and more splits than 256-pixel stages."""
+    nimg, Hp, Wp = shape
+    t = DT[dtype]
+    rowpx = Wp + 4
+    g = torch.Generator().manual_seed(nimg * 1000 + Hp * 10 + Wp)
+    x = torch.randn(nimg, Hp, Wp, 32, generator=g).to(t)                     # conv-2 input (post-pool activations), channel-last
+    dy = (torch.randn(nimg, Hp, Wp, 64, generator=g) * 0.1).to(t)            # gradient of the conv-2 output
+    Q = nimg * (Hp + 2) * rowpx
+    p1 = torch.zeros(Q + 4 * rowpx, 32, dtype=t)
+    d2 = torch.zeros(Q + 4 * rowpx, 64, dtype=t)
+    p1[:Q].view(nimg, Hp + 2, rowpx, 32)[:, 1:Hp + 1, 1:Wp + 1] = x
+    d2[:Q].view(nimg, Hp + 2, rowpx, 64)[:, 1:Hp + 1, 1:Wp + 1] = dy
+    splits = L.lib().eg_conv2d_wgrad_flat_splits(Q, want)
+    assert 1 <= splits <= want
+    partial = torch.full((splits, 64, 384), float("nan"), device=DEV)
+    p1d, d2d = p1.to(DEV), d2.to(DEV)
+    call("eg_conv2d_wgrad_flat", ptr(d2d), ptr(p1d), ptr(partial), Q, Q + 4 * rowpx, rowpx, splits, dtype, 0)
+    dW = torch.full((64, 32, 3, 3), 7.0, device=DEV)
+    call("eg_unpack_conv2d_wgrad", ptr(partial), ptr(dW), splits, 64, 32, 0)
+    torch.cuda.synchronize()
+    ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (64, 32, 3, 3), dy.double().permute(0, 3, 1, 2), padding=1)
+    scale = float(ref.abs().max())
+    assert float((dW.double().cpu() - ref).abs().max()) < 2e-5 * scale + 1e-6, float((dW.double().cpu() - ref).abs().max()) / scale
