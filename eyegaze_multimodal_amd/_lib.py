@@ -166,6 +166,7 @@ SIGNATURES = {
     "eg_unpack_conv2d_wgrad": [_P, _P, _I, _I, _I, _P],
     "eg_conv2d_wgrad_flat": [_P, _P, _P, _L, _L, _I, _I, _I, _P],
     "eg_conv2d_wgrad_flat_splits": [_L, _I],
+    "eg_conv2d_flat": [_P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P],
 }
 _lib = None
 

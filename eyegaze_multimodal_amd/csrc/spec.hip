@@ -341,6 +341,115 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_flat_kernel(const T* __re
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 3 x 3 convolutions on the same flat pixel index (16-bit operands), forward and backward-data alike:
+//     out[g * Wp + x][n] = act(b[n] + sum over the nine taps and CIN channels of in[q + ky * rowpx + kx][c] * W[n][(ky * 4 + kx) * CIN + c]),
+//     q = g * rowpx + x, x < Wp
+// forward: in = p1 (CIN 32), NOUT 64, W = eg_pack_conv2d_weight(transposed = 0), ReLU;  backward-data: in = d2 (CIN 64), NOUT 32,
+// W = the transposed packing (taps flipped), out = dp1.  The segmented-row eg_gemm_nt re-read every input pixel twelve times through
+// L2 (0.37 + 0.58 ms at C = 32); here a stage of QC pixels (+ 64-pixel halo) sits in LDS once and the nine taps are nine row offsets of
+// that image.  A wave owns a quarter of a stage's m-tiles (16 pixels each) and ALL outputs: the 36 weight fragments (NOUT/16 n-tiles
+// x 9 taps x CIN/32 k-steps) stay in registers for the whole launch; an m-tile costs 9 CIN/32 fragment reads (ds_read_b128, chunk
+// index XOR-swizzled by the row) and 36 MFMA.  One third of the MFMA work is the pad slots x >= Wp (never stored); the launches are
+// bound by HBM, not by MFMA.
+// ------------------------------------------------------------------------------------------------
+template <int CIN>
+__device__ __forceinline__ int cf_xoff(int row, int chunk) {
+  constexpr int RPB = 256 / (CIN * 2), CPR = CIN / 8;            // rows per 256-B bank row, 16-B chunks per row
+  return row * (CIN * 2) + ((chunk ^ ((row / RPB) & (CPR - 1))) << 4);
+}
+
+template <typename T, int ACT, int CIN, int NOUT>
+__global__ __launch_bounds__(256, 2) void conv2d_flat_kernel(const T* __restrict__ in, const T* __restrict__ W,
+                                                             const float* __restrict__ bias, T* __restrict__ out, int Q, int in_rows,
+                                                             int rowpx, int Wp, int rows_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename H16<T>::frag frag;
+  constexpr int QC = CIN == 32 ? 256 : 128;                      // pixels per stage
+  constexpr int CPR = CIN / 8, KS = CIN / 32, NT = NOUT / 16;
+  constexpr int NCH = (QC + CW_HALO) * CPR / 256;                // 16-B chunks per thread and stage (5 / 6)
+  constexpr int MTW = QC / 64;                                   // m-tiles per wave and stage
+  static_assert((QC + CW_HALO) * CPR % 256 == 0 && NT * KS == 4, "conv2d_flat_kernel: shape");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int qbeg = blockIdx.x * rows_per_split;
+  const int qend = min(Q, qbeg + rows_per_split);
+
+  frag wf[9][KS][NT];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+        wf[t][ks][i] = *(const frag*)(W + (size_t)(i * 16 + l15) * (12 * CIN) + ((t / 3) * 4 + (t % 3)) * CIN + ks * 32 + 8 * g);
+  float bv[NT][4];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[i][r] = bias ? bias[i * 16 + 4 * g + r] : 0.f;
+  int toff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) toff[t] = (t / 3) * rowpx + (t % 3);
+
+  // staging map: chunk c = tid + 256 i (i < NCH): row c / CPR, 16-B piece c % CPR of the (QC + 64)-row image
+  u32x4 rx[NCH];
+  auto load_stage = [&](int q0) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + 256 * i, row = c / CPR, pc = c % CPR;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      rx[i] = z;
+      if (q0 + row < in_rows) rx[i] = *(const u32x4*)(in + (size_t)(q0 + row) * CIN + pc * 8);
+    }
+  };
+  if (qbeg < qend) load_stage(qbeg);
+  for (int q0 = qbeg; q0 < qend; q0 += QC) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + 256 * i;
+      *(u32x4*)(smem + cf_xoff<CIN>(c / CPR, c % CPR)) = rx[i];
+    }
+    __syncthreads();
+    if (q0 + QC < qend) load_stage(q0 + QC);
+#pragma unroll 1
+    for (int mt = 0; mt < MTW; ++mt) {
+      const int m0 = (wave * MTW + mt) * 16;                      // first pixel of the m-tile within the stage
+      if (q0 + m0 >= qend) break;
+      f32x4 acc[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const frag xf = *(const frag*)(smem + cf_xoff<CIN>(m0 + l15 + toff[t], ks * 4 + g));
+#pragma unroll
+          for (int i = 0; i < NT; ++i) acc[i] = H16<T>::mfma(wf[t][ks][i], xf, acc[i]);
+        }
+      // D[i = n][j = pixel]: lane holds outputs n = 16 i + 4 g + r of pixel m0 + l15
+      const int q = q0 + m0 + l15;
+      const int grp = q / rowpx, x = q - grp * rowpx;
+      if (q < qend && x < Wp) {
+        T* o = out + ((size_t)grp * Wp + x) * NOUT + 4 * g;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[i][r] + bv[i][r];
+            if (ACT == EG_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+          }
+          *(uint2*)(o + i * 16) = make_uint2(H16<T>::pack2(v[0], v[1]), H16<T>::pack2(v[2], v[3]));
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 #define SPEC_DISPATCH(dtype, BF, F16, F32, who)   \
@@ -478,4 +587,31 @@ extern "C" int eg_conv2d_wgrad_flat_splits(long long Q, int want) {
     --splits;
   }
   return splits;
+}
+
+extern "C" int eg_conv2d_flat(const void* in, const void* W, const float* bias, void* out, long long Q, long long in_rows, int rowpx,
+                              int Wp, int cin, int nout, int act, int splits, int dtype, void* stream) {
+  EG_CHECK(in && W && out && Q > 0 && Q < (1ll << 31) - 4096 && in_rows < (1ll << 31) && rowpx >= 4 && 2 * rowpx + 2 <= CW_HALO &&
+           Wp > 0 && Wp <= rowpx && splits > 0, "eg_conv2d_flat: bad arguments");
+  EG_CHECK(dtype == EG_BF16 || dtype == EG_F16, "eg_conv2d_flat: 16-bit operands only (dtype %d); fp32 goes through eg_gemm_nt", dtype);
+  EG_CHECK((cin == 32 && nout == 64) || (cin == 64 && nout == 32), "eg_conv2d_flat: %d -> %d channels (32 -> 64 or 64 -> 32)", cin, nout);
+  EG_CHECK(act == EG_ACT_NONE || act == EG_ACT_RELU, "eg_conv2d_flat: act %d (none or ReLU)", act);
+  EG_CHECK(in_rows >= Q + 2 * rowpx + 2, "eg_conv2d_flat: the input holds %lld pixel rows, the windows of %lld pixels reach %lld", in_rows, Q,
+           Q + 2 * rowpx + 2);
+  const int qc = cin == 32 ? 256 : 128;
+  const long long rps = ((Q + splits - 1) / splits + qc - 1) / qc * qc;
+  const int nblk = (int)((Q + rps - 1) / rps);
+  const int lds = (qc + CW_HALO) * cin * 2;
+  hipStream_t s = (hipStream_t)stream;
+#define EG_CF_LAUNCH(T, A, CI, NO) \
+  hipLaunchKernelGGL((conv2d_flat_kernel<T, A, CI, NO>), dim3(nblk), dim3(256), lds, s, (const T*)in, (const T*)W, bias, (T*)out, (int)Q, \
+                     (int)in_rows, rowpx, Wp, (int)rps)
+#define EG_CF_SHAPE(T) \
+  if (cin == 32) { if (act == EG_ACT_RELU) EG_CF_LAUNCH(T, EG_ACT_RELU, 32, 64); else EG_CF_LAUNCH(T, EG_ACT_NONE, 32, 64); } \
+  else           { if (act == EG_ACT_RELU) EG_CF_LAUNCH(T, EG_ACT_RELU, 64, 32); else EG_CF_LAUNCH(T, EG_ACT_NONE, 64, 32); }
+  if (dtype == EG_BF16) { EG_CF_SHAPE(bf16_t) } else { EG_CF_SHAPE(f16_t) }
+#undef EG_CF_SHAPE
+#undef EG_CF_LAUNCH
+  EG_LAUNCH_CHECK("conv2d_flat");
+  return 0;
 }

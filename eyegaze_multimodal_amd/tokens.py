@@ -12,6 +12,7 @@ from . import _lib as L
 from ._lib import EG_F32, call, ptr, rowmap
 from .engine import SITE_IBSGEN, SITE_IBSTOK, SITE_SPEC, Engine, _align
 
+CONV2_FWD_FLAT = os.environ.get("EYEGAZE_CONV2_FLAT", "1") != "0"           # 0: conv-2 forward / backward-data as segmented-row eg_gemm_nt
 CONV2_WGRAD_FLAT = os.environ.get("EYEGAZE_CONV2_WGRAD_FLAT", "1") != "0"   # 0: the conv-2 weight gradient as an im2col eg_gemm_tn
 ROBUST_BANDS = [(0.5, 45.0), (0.5, 4.0), (4.0, 8.0), (8.0, 13.0), (13.0, 30.0), (30.0, 45.0)]  # D:500-507
 SCALAR_BANDS = [(4.0, 8.0), (8.0, 13.0), (13.0, 30.0), (30.0, 45.0)]                           # D:201-206
@@ -214,8 +215,15 @@ def spec_cnn_forward(eng, pre, p01, conv2, out_ptr, c_map, r_map, residual_ptr):
     call("eg_spec_conv1_fwd", ptr(a["spimg"]), fp.p_ptr(pre + "spec_conv.0.weight"), fp.p_ptr(pre + "spec_conv.0.bias"),
          ptr(a["sp_p1"]), nimg, F, nfr, dt, st)
     row = (Wp + 4) * 32
-    eng.gemm(ptr(a["sp_p1"]), ptr(w["spc2"]), ptr(a["sp_out2"]), sp["rows"], 64, 384, a=rowmap(32, row, Wp), seg=(128, row),
-             bias=fp.p_ptr(pre + "spec_conv.3.bias"), act=L.ACT_RELU)
+    if dt != L.EG_F32 and CONV2_FWD_FLAT and 2 * (Wp + 4) + 2 <= 64:
+        # 16-bit operands: nine row offsets of one LDS image of p1 (csrc/spec.hip) instead of a segmented-row product that re-reads
+        # every pixel twelve times through L2
+        Q = nimg * (Hp + 2) * (Wp + 4)
+        call("eg_conv2d_flat", ptr(a["sp_p1"]), ptr(w["spc2"]), fp.p_ptr(pre + "spec_conv.3.bias"), ptr(a["sp_out2"]), Q,
+             Q + 4 * (Wp + 4), Wp + 4, Wp, 32, 64, L.ACT_RELU, 2 * eng.cus, dt, st)
+    else:
+        eng.gemm(ptr(a["sp_p1"]), ptr(w["spc2"]), ptr(a["sp_out2"]), sp["rows"], 64, 384, a=rowmap(32, row, Wp), seg=(128, row),
+                 bias=fp.p_ptr(pre + "spec_conv.3.bias"), act=L.ACT_RELU)
     if conv2 is not None and conv2._forward_hooks:
         # Grad-CAM contract (5_Metrics/eeg_metrics.py:742-764): a forward hook on spec_conv[3] sees that layer's output
         # (before the ReLU the production GEMM fuses), once per stream, as [B*C, 64, H', W']
@@ -296,7 +304,12 @@ def spec_cnn_backward(eng, pre, dy_ptr, dmap, sc01):
         eng.wgrad(ptr(g["sp_d2"]) + (row64 + 64) * es, ptr(a["sp_p1"]), fp.g_ptr(pre + "spec_conv.3.weight"), rows, 64, 384,
                   y=rowmap(64, row64, Wp), x=rowmap(32, row32, Wp), x_tile_stride=row32, conv2d=(64, 32),
                   out_b=fp.g_ptr(pre + "spec_conv.3.bias"))
-    eng.gemm(ptr(g["sp_d2"]), ptr(w["spc2T"]), ptr(g["sp_dp1"]), rows, 32, 768, a=rowmap(64, row64, Wp), seg=(256, row64))
+    if dt != L.EG_F32 and CONV2_FWD_FLAT and 2 * (Wp + 4) + 2 <= 64:
+        Q = nimg * (Hp + 2) * (Wp + 4)
+        call("eg_conv2d_flat", ptr(g["sp_d2"]), ptr(w["spc2T"]), 0, ptr(g["sp_dp1"]), Q, Q + 4 * (Wp + 4), Wp + 4, Wp, 64, 32, L.ACT_NONE,
+             2 * eng.cus, dt, st)
+    else:
+        eng.gemm(ptr(g["sp_d2"]), ptr(w["spc2T"]), ptr(g["sp_dp1"]), rows, 32, 768, a=rowmap(64, row64, Wp), seg=(256, row64))
     call("eg_spec_conv1_bwd", ptr(a["spimg"]), fp.p_ptr(pre + "spec_conv.0.weight"), fp.p_ptr(pre + "spec_conv.0.bias"),
          ptr(g["sp_dp1"]), ptr(g["sp_part"]), nimg, F, nfr, dt, st)
     call("eg_reduce_partials", ptr(g["sp_part"]), fp.g_ptr(pre + "spec_conv.0.weight"), 288, nimg, 320, 0, st)

@@ -476,6 +476,13 @@ int eg_unpack_conv2d_wgrad(float* partial /* scratch: reduced in place when spli
 int eg_conv2d_wgrad_flat(const void* d2, const void* p1, float* partial, long long Q, long long p1_rows, int rowpx, int splits,
                          int dtype, void* stream);
 int eg_conv2d_wgrad_flat_splits(long long Q, int want);
+/* Conv2d(32,64,3,p1) forward (D:74, + the ReLU of D:75 when act = EG_ACT_RELU; cin 32, nout 64, W = eg_pack_conv2d_weight(transposed 0))
+ * and its backward-data (autograd's grad_input: in = d2, cin 64, nout 32, W = the transposed packing, out = dp1) on the same flat
+ * pixel index, 16-bit operands:
+ *   out[g*Wp + x][n] = act(bias[n] + sum_{ky,kx,c} in[q + ky*rowpx + kx][c] * W[n][(ky*4+kx)*cin + c]), q = g*rowpx + x, x < Wp,
+ * for all Q = nimg*(Hp+2)*rowpx pixel slots; `in` must hold in_rows >= Q + 2*rowpx + 2 readable pixel rows; `splits` = workgroups wanted. */
+int eg_conv2d_flat(const void* in, const void* W, const float* bias, void* out, long long Q, long long in_rows, int rowpx, int Wp,
+                   int cin, int nout, int act, int splits, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

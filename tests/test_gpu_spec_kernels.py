@@ -92,3 +92,61 @@ def test_conv2d_wgrad_flat(shape, want, dtype):
     ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (64, 32, 3, 3), dy.double().permute(0, 3, 1, 2), padding=1)
     scale = float(ref.abs().max())
     assert float((dW.double().cpu() - ref).abs().max()) < 2e-5 * scale + 1e-6, float((dW.double().cpu() - ref).abs().max()) / scale
+
+
+@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16])
+@pytest.mark.parametrize("shape,splits", [((6, 8, 8), 3), ((40, 32, 8), 512), ((3, 8, 4), 1), ((9, 16, 24), 7)])
+def test_conv2d_flat_forward(shape, splits, dtype):
+    """Conv2d(32, 64, 3, padding=1) + ReLU from the padded pixel rows against torch's conv2d in float64 on the same rounded operands
+    (weights packed by eg_pack_conv2d_weight); every row of out2 [nimg, Hp+2, Wp, 64] is written, the image rows are compared."""
+    nimg, Hp, Wp = shape
+    t = DT[dtype]
+    rowpx = Wp + 4
+    g = torch.Generator().manual_seed(nimg * 1000 + Hp * 10 + Wp + 1)
+    x = torch.randn(nimg, Hp, Wp, 32, generator=g).to(t)
+    wt = (torch.randn(64, 32, 3, 3, generator=g) * 0.1)
+    bias = torch.randn(64, generator=g)
+    Q = nimg * (Hp + 2) * rowpx
+    p1 = torch.zeros(Q + 4 * rowpx, 32, dtype=t)
+    p1[:Q].view(nimg, Hp + 2, rowpx, 32)[:, 1:Hp + 1, 1:Wp + 1] = x
+    wd = torch.zeros(64, 384, device=DEV, dtype=t)
+    call("eg_pack_conv2d_weight", ptr(wt.to(DEV)), ptr(wd), 64, 32, 0, dtype, 0)
+    out2 = torch.full((nimg, Hp + 2, Wp, 64), 7.0, device=DEV, dtype=t)
+    p1d, bd = p1.to(DEV), bias.to(DEV)
+    call("eg_conv2d_flat", ptr(p1d), ptr(wd), ptr(bd), ptr(out2), Q, Q + 4 * rowpx, rowpx, Wp, 32, 64, L.ACT_RELU, splits, dtype, 0)
+    torch.cuda.synchronize()
+    ref = torch.relu(torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wd.cpu().double().view(64, 3, 4, 32)[:, :, :3].permute(0, 3, 1, 2),
+                                                bias.double(), padding=1)).permute(0, 2, 3, 1)
+    # the flat index places output pixel (y, x) of the reference's padded convolution one row and one pixel up-left of its window's
+    # origin: out2 row y holds the window whose top-left corner is padded row y, i.e. image row y (the layout eg_spec_avgpool_fwd reads)
+    got = out2[:, :Hp].double().cpu()
+    tol = 2e-2 if dtype == L.EG_BF16 else 3e-3
+    torch.testing.assert_close(got, ref, rtol=tol, atol=tol)
+    assert float((out2[:, Hp:].float() - 7.0).abs().min()) > 0            # the layout's two pad rows are written too (values unused)
+
+
+@pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16])
+@pytest.mark.parametrize("shape,splits", [((6, 8, 8), 3), ((40, 32, 8), 512), ((3, 8, 4), 1), ((9, 16, 24), 7)])
+def test_conv2d_flat_backward_data(shape, splits, dtype):
+    """grad_input of Conv2d(32, 64, 3, padding=1): dp1 [nimg, Hp+2, Wp, 32] from the padded gradient rows d2 and the transposed weight
+    packing, against torch's conv2d_input in float64 on the same rounded operands."""
+    nimg, Hp, Wp = shape
+    t = DT[dtype]
+    rowpx = Wp + 4
+    g = torch.Generator().manual_seed(nimg * 1000 + Hp * 10 + Wp + 2)
+    dy = torch.randn(nimg, Hp, Wp, 64, generator=g).to(t)
+    wt = (torch.randn(64, 32, 3, 3, generator=g) * 0.1)
+    Q = nimg * (Hp + 2) * rowpx
+    d2 = torch.zeros(Q + 4 * rowpx, 64, dtype=t)
+    d2[:Q].view(nimg, Hp + 2, rowpx, 64)[:, 1:Hp + 1, 1:Wp + 1] = dy
+    wT = torch.zeros(32, 768, device=DEV, dtype=t)
+    call("eg_pack_conv2d_weight", ptr(wt.to(DEV)), ptr(wT), 64, 32, 1, dtype, 0)
+    dp1 = torch.full((nimg, Hp + 2, Wp, 32), 7.0, device=DEV, dtype=t)
+    d2d = d2.to(DEV)
+    call("eg_conv2d_flat", ptr(d2d), ptr(wT), 0, ptr(dp1), Q, Q + 4 * rowpx, rowpx, Wp, 64, 32, L.ACT_NONE, splits, dtype, 0)
+    torch.cuda.synchronize()
+    # the rounded weights, back in [n][c][ky][kx]: the transposed packing holds w[n][c][2-ky][2-kx] at [c][(ky*4+kx)*64 + n]
+    wr = wT.cpu().double().view(32, 3, 4, 64)[:, :, :3].flip(1, 2).permute(3, 0, 1, 2)
+    ref = torch.nn.grad.conv2d_input((nimg, 32, Hp, Wp), wr, dy.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    tol = 2e-2 if dtype == L.EG_BF16 else 3e-3
+    torch.testing.assert_close(dp1[:, :Hp].double().cpu(), ref, rtol=tol, atol=tol * float(ref.abs().max()))
