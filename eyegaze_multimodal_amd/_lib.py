@@ -164,7 +164,7 @@ SIGNATURES = {
     "eg_spec_avgpool_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "eg_pack_conv2d_weight": [_P, _P, _I, _I, _I, _I, _P],
     "eg_unpack_conv2d_wgrad": [_P, _P, _I, _I, _I, _P],
-    "eg_conv2d_wgrad_flat": [_P, _P, _P, _L, _L, _I, _I, _I, _P],
+    "eg_conv2d_wgrad_flat": [_P, _P, _P, _P, _L, _L, _I, _I, _I, _P],
     "eg_conv2d_wgrad_flat_splits": [_L, _I],
     "eg_conv2d_flat": [_P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P],
 }

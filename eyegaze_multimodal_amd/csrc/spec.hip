@@ -239,8 +239,9 @@ __device__ __forceinline__ int cw_xoff(int row, int slot) { return row * 64 + ((
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void conv2d_wgrad_flat_kernel(const T* __restrict__ d2, const T* __restrict__ p1,
-                                                                   float* __restrict__ partial, long long Q, long long p1_rows,
-                                                                   int rowpx, long long rows_per_split) {
+                                                                   float* __restrict__ partial, float* __restrict__ bias_partial,
+                                                                   long long Q, long long p1_rows, int rowpx,
+                                                                   long long rows_per_split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename H16<T>::frag frag;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -249,6 +250,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_flat_kernel(const T* __re
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cj = wave & 1, tap0 = (wave >> 1) * 5, ntap = 5 - (wave >> 1);
+  // wave 3 has a free fifth accumulator slot: with an all-ones X fragment it holds the column sums of the gradient rows = the bias
+  // gradient (the pads of d2 are zero), at four MFMA per step and no extra LDS or HBM traffic (a separate column-sum pass re-read d2)
+  const bool bias_wave = bias_partial != nullptr && wave == 3;
   const long long qbeg = (long long)blockIdx.x * rows_per_split;
   const long long qend = qbeg + rows_per_split < Q ? qbeg + rows_per_split : Q;
   const T* const yb = d2 + (size_t)(rowpx + 1) * 64;             // gradient of output pixel q
@@ -325,8 +329,19 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_flat_kernel(const T* __re
           for (int i = 0; i < 4; ++i) acc[t][i] = H16<T>::mfma(xf, yf[i], acc[t][i]);
         }
       }
+      if (bias_wave) {
+        const uint32_t one2 = H16<T>::pack2(1.f, 1.f);
+        const u32x4 ones = {one2, one2, one2, one2};
+        const frag xf = __builtin_bit_cast(frag, ones);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4][i] = H16<T>::mfma(xf, yf[i], acc[4][i]);
+      }
     }
     __syncthreads();
+  }
+  if (bias_wave && lane < 16) {                                   // every row of the ones-product holds the sums: lane g = 0, r = 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias_partial[(size_t)blockIdx.x * 64 + i * 16 + lane] = acc[4][i][0];
   }
   // D[i = channel][j = n]: lane holds 4 consecutive channels (4 g + r) of column n = lane & 15
   float* out = partial + (size_t)blockIdx.x * (64 * 384);
@@ -550,8 +565,8 @@ extern "C" int eg_unpack_conv2d_wgrad(float* partial, float* dW, int splits, int
   return 0;
 }
 
-extern "C" int eg_conv2d_wgrad_flat(const void* d2, const void* p1, float* partial, long long Q, long long p1_rows, int rowpx,
-                                    int splits, int dtype, void* stream) {
+extern "C" int eg_conv2d_wgrad_flat(const void* d2, const void* p1, float* partial, float* bias_partial, long long Q, long long p1_rows,
+                                    int rowpx, int splits, int dtype, void* stream) {
   EG_CHECK(d2 && p1 && partial && Q > 0 && rowpx >= 4 && 2 * rowpx + 2 <= CW_HALO && splits > 0, "eg_conv2d_wgrad_flat: bad arguments");
   EG_CHECK(p1_rows >= Q + 2 * rowpx + 2, "eg_conv2d_wgrad_flat: p1 holds %lld pixel rows, the windows of %lld pixels reach %lld", p1_rows, Q,
            Q + 2 * rowpx + 2);
@@ -569,10 +584,10 @@ extern "C" int eg_conv2d_wgrad_flat(const void* d2, const void* p1, float* parti
   hipStream_t s = (hipStream_t)stream;
   if (dtype == EG_BF16)
     hipLaunchKernelGGL(conv2d_wgrad_flat_kernel<bf16_t>, dim3(splits), dim3(256), CW_YB + CW_XB, s, (const bf16_t*)d2, (const bf16_t*)p1,
-                       partial, Q, p1_rows, rowpx, rps);
+                       partial, bias_partial, Q, p1_rows, rowpx, rps);
   else
     hipLaunchKernelGGL(conv2d_wgrad_flat_kernel<f16_t>, dim3(splits), dim3(256), CW_YB + CW_XB, s, (const f16_t*)d2, (const f16_t*)p1,
-                       partial, Q, p1_rows, rowpx, rps);
+                       partial, bias_partial, Q, p1_rows, rowpx, rps);
   EG_LAUNCH_CHECK("conv2d_wgrad_flat");
   return 0;
 }

@@ -295,11 +295,11 @@ def spec_cnn_backward(eng, pre, dy_ptr, dmap, sc01):
         # fetched p1 twelve times and d2 three times through L2 (0.93 ms of the C = 32 step)
         Q = nimg * (Hp + 2) * (Wp + 4)
         splits = L.lib().eg_conv2d_wgrad_flat_splits(Q, min(2 * eng.cus, eng.tn_cap // (64 * 384)))
-        call("eg_conv2d_wgrad_flat", ptr(g["sp_d2"]), ptr(a["sp_p1"]), ptr(g["partial"]), Q, Q + 4 * (Wp + 4), Wp + 4, splits, dt, st)
+        # (the bias gradient rides in the same launch: column sums of the gradient rows as one more MFMA product; cspart holds 512 x 768)
+        call("eg_conv2d_wgrad_flat", ptr(g["sp_d2"]), ptr(a["sp_p1"]), ptr(g["partial"]), ptr(g["cspart"]), Q, Q + 4 * (Wp + 4), Wp + 4,
+             splits, dt, st)
         call("eg_unpack_conv2d_wgrad", ptr(g["partial"]), fp.g_ptr(pre + "spec_conv.3.weight"), splits, 64, 32, st)
-        nblk = min(512, (rows + 63) // 64)
-        call("eg_colsum", ptr(g["sp_d2"]) + (row64 + 64) * es, rowmap(64, row64, Wp), rows, 64, ptr(g["cspart"]), nblk, dt, st)
-        call("eg_reduce_partials", ptr(g["cspart"]), fp.g_ptr(pre + "spec_conv.3.bias"), 64, nblk, 64, 0, st)
+        call("eg_reduce_partials", ptr(g["cspart"]), fp.g_ptr(pre + "spec_conv.3.bias"), 64, splits, 64, 0, st)
     else:
         eng.wgrad(ptr(g["sp_d2"]) + (row64 + 64) * es, ptr(a["sp_p1"]), fp.g_ptr(pre + "spec_conv.3.weight"), rows, 64, 384,
                   y=rowmap(64, row64, Wp), x=rowmap(32, row32, Wp), x_tile_stride=row32, conv2d=(64, 32),

@@ -472,9 +472,10 @@ int eg_unpack_conv2d_wgrad(float* partial /* scratch: reduced in place when spli
  * (16-bit operands): partial[split][n][(ky*4+kx)*32 + c] = sum over the split's q of d2[q + rowpx + 1][n] * p1[q + ky*rowpx + kx][c],
  * Q = nimg*(Hp+2)*rowpx pixels, rowpx = Wp + 4.  The pads of d2 must be zero (eg_spec_avgpool_bwd writes interiors only); p1 must hold
  * p1_rows >= Q + 2*rowpx + 2 readable pixel rows.  The slabs are the ones eg_unpack_conv2d_wgrad reduces (pad taps kx = 3 are not
- * written).  eg_conv2d_wgrad_flat_splits: the largest split count <= want whose 256-pixel-aligned splits all own pixels. */
-int eg_conv2d_wgrad_flat(const void* d2, const void* p1, float* partial, long long Q, long long p1_rows, int rowpx, int splits,
-                         int dtype, void* stream);
+ * written).  bias_partial (optional): per split the column sums of the gradient rows = autograd's grad_bias, for eg_reduce_partials.
+ * eg_conv2d_wgrad_flat_splits: the largest split count <= want whose 256-pixel-aligned splits all own pixels. */
+int eg_conv2d_wgrad_flat(const void* d2, const void* p1, float* partial, float* bias_partial /* [splits][64] or NULL */, long long Q,
+                         long long p1_rows, int rowpx, int splits, int dtype, void* stream);
 int eg_conv2d_wgrad_flat_splits(long long Q, int want);
 /* Conv2d(32,64,3,p1) forward (D:74, + the ReLU of D:75 when act = EG_ACT_RELU; cin 32, nout 64, W = eg_pack_conv2d_weight(transposed 0))
  * and its backward-data (autograd's grad_input: in = d2, cin 64, nout 32, W = the transposed packing, out = dp1) on the same flat

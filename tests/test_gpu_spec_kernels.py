@@ -85,13 +85,23 @@ def test_conv2d_wgrad_flat(shape, want, dtype):
     assert 1 <= splits <= want
     partial = torch.full((splits, 64, 384), float("nan"), device=DEV)
     p1d, d2d = p1.to(DEV), d2.to(DEV)
-    call("eg_conv2d_wgrad_flat", ptr(d2d), ptr(p1d), ptr(partial), Q, Q + 4 * rowpx, rowpx, splits, dtype, 0)
+    bpart = torch.full((splits, 64), float("nan"), device=DEV)
+    call("eg_conv2d_wgrad_flat", ptr(d2d), ptr(p1d), ptr(partial), ptr(bpart), Q, Q + 4 * rowpx, rowpx, splits, dtype, 0)
     dW = torch.full((64, 32, 3, 3), 7.0, device=DEV)
     call("eg_unpack_conv2d_wgrad", ptr(partial), ptr(dW), splits, 64, 32, 0)
     torch.cuda.synchronize()
     ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (64, 32, 3, 3), dy.double().permute(0, 3, 1, 2), padding=1)
     scale = float(ref.abs().max())
     assert float((dW.double().cpu() - ref).abs().max()) < 2e-5 * scale + 1e-6, float((dW.double().cpu() - ref).abs().max()) / scale
+    refb = dy.double().sum((0, 1, 2))                                       # grad_bias = column sums of the gradient rows
+    torch.testing.assert_close(bpart.double().sum(0).cpu(), refb, rtol=2e-5, atol=2e-5 * float(refb.abs().max()) + 1e-6)
+    # without the bias slot the same weight-gradient slabs come out
+    partial2 = torch.full_like(partial, float("nan"))
+    call("eg_conv2d_wgrad_flat", ptr(d2d), ptr(p1d), ptr(partial2), 0, Q, Q + 4 * rowpx, rowpx, splits, dtype, 0)
+    dW2 = torch.zeros_like(dW)
+    call("eg_unpack_conv2d_wgrad", ptr(partial2), ptr(dW2), splits, 64, 32, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(dW, dW2)
 
 
 @pytest.mark.parametrize("dtype", [L.EG_BF16, L.EG_F16])
