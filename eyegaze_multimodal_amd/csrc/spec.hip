@@ -34,21 +34,35 @@ __global__ __launch_bounds__(256) void spec_conv1_fwd_kernel(const float* __rest
   for (int i = 0; i < 9; ++i) wk[i] = wl[ch * 9 + i];
   const float bb = bl[ch];
   T* ob = p1 + (size_t)im * (Hp + 2) * (Wp + 4) * C1;
-  for (int cell = threadIdx.x >> 5; cell < Hp * Wp; cell += 8) {
-    const int y = cell / Wp, x = cell % Wp;
-    float best = 0.f;  // ReLU floor: max(relu(a_i)) = max(0, max a_i)
+  // a 32-lane group walks pooled rows grp, grp + 8, ... left to right: the 4 x 4 input patch of a cell slides by two columns, so a
+  // cell costs 8 LDS reads and no index arithmetic beyond two pointer bumps (the cell = y * Wp + x form spent two thirds of its
+  // instructions on division and addressing: 267 us at C = 32).  Per output the multiply-add chain is unchanged.
+  for (int y = threadIdx.x >> 5; y < Hp; y += 8) {
+    const float* r0 = I + (2 * y) * PW;
+    T* orow = ob + ((size_t)(y + 1) * (Wp + 4) + 1) * C1 + ch;
+    float pt[4][4];
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
+    for (int r = 0; r < 4; ++r) { pt[r][2] = r0[r * PW]; pt[r][3] = r0[r * PW + 1]; }
+    for (int x = 0; x < Wp; ++x) {
 #pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        float a = bb;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) a = fmaf(wk[ky * 3 + kx], I[(2 * y + dy + ky) * PW + (2 * x + dx + kx)], a);
-        best = fmaxf(best, a);
+      for (int r = 0; r < 4; ++r) {
+        pt[r][0] = pt[r][2]; pt[r][1] = pt[r][3];
+        pt[r][2] = r0[r * PW + 2 * x + 2]; pt[r][3] = r0[r * PW + 2 * x + 3];
       }
-    Elem<T>::st(ob + ((size_t)(y + 1) * (Wp + 4) + (x + 1)) * C1 + ch, best);
+      float best = 0.f;  // ReLU floor: max(relu(a_i)) = max(0, max a_i)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          float a = bb;
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) a = fmaf(wk[ky * 3 + kx], pt[dy + ky][dx + kx], a);
+          best = fmaxf(best, a);
+        }
+      Elem<T>::st(orow + (size_t)x * C1, best);
+    }
   }
 }
 
@@ -79,28 +93,42 @@ __global__ __launch_bounds__(256) void spec_conv1_bwd_kernel(const float* __rest
   for (int i = 0; i < 10; ++i) acc[i] = 0.f;
   const float bb = bl[ch];
   const T* gb = dp1 + (size_t)im * (Hp + 2) * Wp * C1;
-  for (int cell = grp; cell < Hp * Wp; cell += 8) {
-    const int y = cell / Wp, x = cell % Wp;
-    float best = -INFINITY;
-    int by = 0, bx = 0;
+  // rows grp, grp + 8, ... left to right with a sliding 4 x 4 patch, as the forward kernel.  (The cell = y * Wp + x form gave a group
+  // the cells grp, grp + 8, ...; the eight fp32 partial sums per channel now group the cells by pooled row -- equal to rounding.)
+  for (int y = grp; y < Hp; y += 8) {
+    const float* r0 = I + (2 * y) * PW;
+    const T* grow = gb + (size_t)y * Wp * C1 + ch;
+    float pt[4][4];
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
+    for (int r = 0; r < 4; ++r) { pt[r][2] = r0[r * PW]; pt[r][3] = r0[r * PW + 1]; }
+    for (int x = 0; x < Wp; ++x) {
+      const float g = Elem<T>::ld(grow + (size_t)x * C1);        // requested before the recomputation, used after it
 #pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        float a = bb;
+      for (int r = 0; r < 4; ++r) {
+        pt[r][0] = pt[r][2]; pt[r][1] = pt[r][3];
+        pt[r][2] = r0[r * PW + 2 * x + 2]; pt[r][3] = r0[r * PW + 2 * x + 3];
+      }
+      float best = -INFINITY;
+      int by = 0, bx = 0;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          float a = bb;
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) a = fmaf(wk[ky * 3 + kx], pt[dy + ky][dx + kx], a);
+          if (a > best) { best = a; by = dy; bx = dx; }
+        }
+      if (best > 0.f) {
+        const float* q = r0 + by * PW + 2 * x + bx;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) a = fmaf(wk[ky * 3 + kx], I[(2 * y + dy + ky) * PW + (2 * x + dx + kx)], a);
-        if (a > best) { best = a; by = dy; bx = dx; }
+          for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = fmaf(g, q[ky * PW + kx], acc[ky * 3 + kx]);
+        acc[9] += g;
       }
-    if (best > 0.f) {
-      const float g = Elem<T>::ld(gb + ((size_t)y * Wp + x) * C1 + ch);
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = fmaf(g, I[(2 * y + by + ky) * PW + (2 * x + bx + kx)], acc[ky * 3 + kx]);
-      acc[9] += g;
     }
   }
 #pragma unroll
