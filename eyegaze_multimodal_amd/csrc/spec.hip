@@ -397,10 +397,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_flat_kernel(const T* __re
 // index XOR-swizzled by the row) and 36 MFMA.  One third of the MFMA work is the pad slots x >= Wp (never stored); the launches are
 // bound by HBM, not by MFMA.
 // ------------------------------------------------------------------------------------------------
+// LDS image of the input pixels, conflict-free for ds_read_b128 at EVERY row offset (the nine taps shift the rows a fragment reads;
+// the instruction serves its lanes in the four 16-lane groups {0-3, 12-15, 20-27}, ...: checked by enumeration over all offsets):
+// 32 channels: 64-B rows at a 96-B pitch, no swizzle;  64 channels: 128-B rows, 16-B chunk index XOR (row & 7).
+// (The first form -- chunk ^ ((row / rows-per-bank-row) & mask) -- was two ways conflicted on every read: SQ_LDS_BANK_CONFLICT 41 %.)
+template <int CIN> struct CfImg;
+template <> struct CfImg<32> { static constexpr int PITCH = 96; };
+template <> struct CfImg<64> { static constexpr int PITCH = 128; };
 template <int CIN>
 __device__ __forceinline__ int cf_xoff(int row, int chunk) {
-  constexpr int RPB = 256 / (CIN * 2), CPR = CIN / 8;            // rows per 256-B bank row, 16-B chunks per row
-  return row * (CIN * 2) + ((chunk ^ ((row / RPB) & (CPR - 1))) << 4);
+  return CIN == 32 ? row * 96 + (chunk << 4) : row * 128 + ((chunk ^ (row & 7)) << 4);
 }
 
 template <typename T, int ACT, int CIN, int NOUT>
@@ -644,7 +650,7 @@ extern "C" int eg_conv2d_flat(const void* in, const void* W, const float* bias, 
   const int qc = cin == 32 ? 256 : 128;
   const long long rps = ((Q + splits - 1) / splits + qc - 1) / qc * qc;
   const int nblk = (int)((Q + rps - 1) / rps);
-  const int lds = (qc + CW_HALO) * cin * 2;
+  const int lds = (qc + CW_HALO) * (cin == 32 ? CfImg<32>::PITCH : CfImg<64>::PITCH);
   hipStream_t s = (hipStream_t)stream;
 #define EG_CF_LAUNCH(T, A, CI, NO) \
   hipLaunchKernelGGL((conv2d_flat_kernel<T, A, CI, NO>), dim3(nblk), dim3(256), lds, s, (const T*)in, (const T*)W, bias, (T*)out, (int)Q, \
