@@ -10,7 +10,7 @@
 // of LDS each): the two row halves of a CU share nothing, so they run as independent workgroups whose phases drift apart -- one's
 // MFMA bursts sit beside the other's epilogue / barrier / store phases (as one 512-thread workgroup every wave hit the same
 // barrier and the matrix pipe idled through each epilogue):
-//   * the A tile [80 x 256] stays in LDS for the whole launch (40 KB, LDS-DMA, 16-B chunks XOR-swizzled by row & 7); it is the
+//   * the A tile [80 x 256] stays in LDS for the whole launch (40 KB, LDS-DMA, 16-B chunks XOR-swizzled by 2 (row & 7)); it is the
 //     B operand of every product-1 MFMA and, in the forward pass, the residual of the final epilogue (no second HBM read);
 //   * the hidden dimension is walked in chunks of 128 columns: product 1 gives a wave 80 x 32 of the chunk (5 x 2 accumulator
 //     tiles over K = 256), its epilogue writes the 16-bit chunk into one of TWO 20 KB LDS buffers (one barrier per chunk), from
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
   const int nch = p.F / FC;
 
   // ---- A tile: instruction q moves rows 2q, 2q+1 (lane -> row half lane/32, LDS chunk position lane%32 holding global chunk
-  //      pos ^ (row & 7)); wave w issues q = w, w+4, .. (10 each) ----
+  //      pos ^ 2 (row & 7)); wave w issues q = w, w+4, .. (10 each) ----
   {
     const int half = lane >> 5, pos = lane & 31;
 #pragma unroll
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
       const int q = wn + 4 * i;
       const int r = 2 * q + half;
       const int row = min(m0 + r, p.M - 1);
-      fdma16((const char*)(p.A + (size_t)row * (size_t)p.lda) + ((pos ^ (r & 7)) << 4), xt + q * 1024);
+      fdma16((const char*)(p.A + (size_t)row * (size_t)p.lda) + ((pos ^ ((r & 7) << 1)) << 4), xt + q * 1024);
     }
   }
 
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
     if (nch > 1) gnext1 = bits_p[256];
   }
   const int rbase = l15;                                     // row of tile i within the workgroup: rbase + 16 i
-  const int sw7 = l15 & 7;
+  const int sw7 = (l15 & 7) << 1;      // chunk ^ 2 (row & 7): free of bank conflicts under ds_read_b128's lane groups on 256-B and 512-B rows
+                                        // (chunk ^ (row & 7) is two ways conflicted there: SQ_LDS_BANK_CONFLICT 44 % of the LDS cycles)
   // epilogue-1 lane constants: byte offset of this lane's 8-B slot (row l15, hidden column 32 wn + 16 j + 4 g4 of the chunk) in the
   // swizzled chunk image -- tile row i adds the immediate 4096 i -- and the dropout PAIR index of (row m0 + l15, column 32 wn + 4 g4)
   int ha[2];
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
 #pragma unroll
     for (int ps = 0; ps < 5; ++ps) {
       const int r = 16 * ps + tq, ch = tid & 15;
-      const u32x4 o = *(const u32x4*)(hc + r * 256 + ((ch ^ (r & 7)) << 4));
+      const u32x4 o = *(const u32x4*)(hc + r * 256 + ((ch ^ ((r & 7) << 1)) << 4));
       if (m0 + r < p.M) *(u32x4*)(p.H + (size_t)(m0 + r) * (size_t)p.ldh + FC * c + 8 * ch) = o;
     }
 
@@ -314,8 +315,8 @@ __global__ __launch_bounds__(256, 2) void ffn_chain_kernel(FfnArgs<T> p) {
     eraw[i][1] = (u32x4){0u, 0u, 0u, 0u};
     const int r = 16 * i + er;
     if (p.res_in_lds) {
-      eraw[i][0] = *(const u32x4*)(xt + r * 512 + ((((n >> 3)) ^ (r & 7)) << 4));
-      eraw[i][1] = *(const u32x4*)(xt + r * 512 + ((((n >> 3) + 1) ^ (r & 7)) << 4));
+      eraw[i][0] = *(const u32x4*)(xt + r * 512 + ((((n >> 3)) ^ ((r & 7) << 1)) << 4));
+      eraw[i][1] = *(const u32x4*)(xt + r * 512 + ((((n >> 3) + 1) ^ ((r & 7) << 1)) << 4));
     } else if (p.residual && m0 + r < p.M) {
       const T* pe = p.residual + (size_t)(m0 + r) * (size_t)p.ldr + n;
       eraw[i][0] = *(const u32x4*)pe;
