@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_fwd_kernel(ABArgs<T> p) {
   const int nkt = NKTX ? NKTX : (S + 15) >> 4;   // key / query tiles in use (<= 5)
 
   // ---- x tile: instruction q moves rows 2q, 2q+1 (lane -> row half lane/32, LDS chunk position lane%32 holding global chunk
-  //      pos ^ (row & 7)); rows beyond S repeat row S-1 (finite values that never reach a stored result) ----
+  //      pos ^ 2 (row & 7)); rows beyond S repeat row S-1 (finite values that never reach a stored result) ----
   {
     const int half = lane >> 5, pos = lane & 31;
 #pragma unroll
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_fwd_kernel(ABArgs<T> p) {
       const int q = wn + 4 * i;
       const int r = 2 * q + half;
       const int row = min(r, S - 1);
-      ab_dma16((const char*)(p.X + (row0 + row) * AD) + ((pos ^ (r & 7)) << 4), xt + q * 1024);
+      ab_dma16((const char*)(p.X + (row0 + row) * AD) + ((pos ^ ((r & 7) << 1)) << 4), xt + q * 1024);
     }
   }
   // rows 80..95 of both v images are read by the last key pair's transposed fragments and never written: zero them once
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void attn_block_fwd_kernel(ABArgs<T> p) {
     // the loop (loop-invariant address registers pushed the kernel past its 256-register budget and into scratch)
     int lv = lane;
     asm volatile("" : "+v"(lv));
-    const int l15 = lv & 15, g4 = lv >> 4, sw7 = l15 & 7;
+    const int l15 = lv & 15, g4 = lv >> 4, sw7 = (l15 & 7) << 1;   // chunk ^ 2 (row & 7): conflict-free under ds_read_b128's lane groups on 512-B rows (ffn.hip)
     // ================= P1: q|k|v columns of heads 2c, 2c+1 =================
     // column tile t = 3 wn + j of the chunk: head t / 6, part (t % 6) / 2 (q, k, v), 16-column half t % 2
     f32x4 acc1[5][3];
@@ -382,8 +382,8 @@ __global__ __launch_bounds__(256, 2) void attn_block_fwd_kernel(ABArgs<T> p) {
         eg_dropout_run<8>(v0, p.d1, seed_lo, seed_hi, idx);
         eg_dropout_run<8>(v1, p.d1, seed_lo, seed_hi, idx + 8);
       }
-      const u32x4 e0 = *(const u32x4*)(xt + r * 512 + ((((n >> 3)) ^ (r & 7)) << 4));
-      const u32x4 e1 = *(const u32x4*)(xt + r * 512 + ((((n >> 3) + 1) ^ (r & 7)) << 4));
+      const u32x4 e0 = *(const u32x4*)(xt + r * 512 + ((((n >> 3)) ^ ((r & 7) << 1)) << 4));
+      const u32x4 e1 = *(const u32x4*)(xt + r * 512 + ((((n >> 3) + 1) ^ ((r & 7) << 1)) << 4));
       float rv[16];
       load8((const T*)&e0, rv);
       load8((const T*)&e1, rv + 8);

@@ -9,7 +9,7 @@
 // the fragment loads in the waves' in-order vmcnt queues, the reason the streamed form of this tile was dropped).
 //
 // One 256-thread workgroup per 80 rows, two per CU (80 KB of LDS):
-//   1. LDS-DMA: dy rows -> tile Y, x rows -> tile X ([80][512 B], 16-B pieces XOR-swizzled by row & 7);
+//   1. LDS-DMA: dy rows -> tile Y, x rows -> tile X ([80][512 B], 16-B pieces XOR-swizzled by 2 (row & 7));
 //   2. a half-wave per row (32 lanes x 8 elements), rows hw, hw + 8, ..: EXACTLY layernorm_bwd256_kernel's arithmetic and reduction
 //      order (dr and dyo are bit-identical to eg_layernorm_bwd's); dr and dyo leave as 512-B rows, dyo also replaces the dy piece in
 //      tile Y in place -- tile Y becomes the product's A operand;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_proj_kernel(LnProjArgs<T> p) {
   const int m0 = blockIdx.x * PR;
 
   // ---- 1. both tiles by LDS-DMA: instruction q moves rows 2q, 2q + 1 (lane -> row half lane / 32, piece lane % 32 holding the row's
-  //         piece pos ^ (row & 7)); wave w issues q = w, w + 4, .. ----
+  //         piece pos ^ 2 (row & 7)); wave w issues q = w, w + 4, .. ----
   {
     const int half = lane >> 5, pos = lane & 31;
 #pragma unroll
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_proj_kernel(LnProjArgs<T> p) {
       const int q = wn + 4 * i;
       const int r = 2 * q + half;
       const size_t row = (size_t)min(m0 + r, p.M - 1);
-      const int sw = (pos ^ (r & 7)) << 4;
+      const int sw = (pos ^ ((r & 7) << 1)) << 4;
       pdma16((const char*)(p.dy + row * PD) + sw, ty + q * 1024);
       pdma16((const char*)(p.x + row * PD) + sw, tx + q * 1024);
     }
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_proj_kernel(LnProjArgs<T> p) {
     const int r = hw + 8 * j;
     const int m = m0 + r;
     const bool ok = m < p.M;
-    char* const py = ty + r * 512 + ((l ^ (r & 7)) << 4);
-    const char* const px = tx + r * 512 + ((l ^ (r & 7)) << 4);
+    char* const py = ty + r * 512 + ((l ^ ((r & 7) << 1)) << 4);
+    const char* const px = tx + r * 512 + ((l ^ ((r & 7) << 1)) << 4);
     float xv[8], dv[8];
     load8((const T*)px, xv);
     load8((const T*)py, dv);
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_proj_kernel(LnProjArgs<T> p) {
   for (int i = 0; i < 5; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int sw7 = l15 & 7;
+  const int sw7 = (l15 & 7) << 1;      // chunk ^ 2 (row & 7): conflict-free under ds_read_b128's lane groups on 512-B rows (ffn.hip)
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     frag xf[5];
